@@ -1,0 +1,152 @@
+/* libyolohead — MI355X (gfx950) detection-head path of YOLO-TF behind a C ABI.
+ *
+ * The reference (Stick-To/YOLO-TF) has no FFI of its own: the path is inline
+ * TensorFlow graph code inside YOLOv3._build_graph / YOLOv2._build_graph.  Each
+ * entry point below names the graph region it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative yh_status otherwise;
+ *    yh_last_error() gives the thread-local message of the last failure;
+ *    nothing throws across this boundary;
+ *  - every `const float*` / `float*` / `int32_t*` / `void* workspace` argument
+ *    is a DEVICE pointer owned by the caller unless marked "host";
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    all work is enqueued on it and no entry point synchronises with the host;
+ *  - the library holds no mutable global state; calls on different
+ *    (device, stream, workspace) triples may run concurrently;
+ *  - heads are the NHWC head tensors [B][H][W][P*(C+5)] fp32, one per scale,
+ *    channel order per prior = C class logits, t_y, t_x, t_h, t_w, objectness
+ *    (YOLOv3.py:95-102, YOLOv2.py:96-100); `heads` itself is a HOST array of
+ *    num_scales device pointers; each must be 16-byte aligned;
+ *  - box rows of an image are ordered scale 0, 1, 2 ... and (y*W + x)*P + p
+ *    inside a scale (YOLOv3.py:320-349); boxes are (y1, x1, y2, x2).
+ */
+#ifndef YOLOHEAD_H
+#define YOLOHEAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_MAX_SCALES 4
+#define YH_MAX_PRIORS 16
+#define YH_MAX_CLASSES 4096          /* class id takes 12 bits of a candidate key */
+#define YH_MAX_BOXES_PER_IMAGE (1 << 20) /* box index takes 20 bits of a candidate key */
+#define YH_MAX_NMS_BOXES 512         /* upper bound of nms_max_boxes */
+
+typedef enum yh_status {
+    YH_OK = 0,
+    YH_ERR_INVALID_ARG = -1,
+    YH_ERR_NO_DEVICE = -2,
+    YH_ERR_HIP = -3,
+    YH_ERR_WORKSPACE = -4,
+    YH_ERR_LIMIT = -5,
+    YH_ERR_ALIGN = -6
+} yh_status;
+
+/* bits of the device-side status word written by yh_detect / yh_nms */
+#define YH_STATUS_CANDIDATE_OVERFLOW 1 /* an image had more candidates than max_candidates; result invalid for it */
+
+/* Geometry of the head, the data that distinguishes YOLOv3 from YOLOv2:
+ *  prior_hw  : (h, w) in grid units.  YOLOv3: config priors / [8,16,32] with
+ *              list entry 0 paired with the first grid (YOLOv3.py:37-41,
+ *              111-113); YOLOv2: config priors unscaled (YOLOv2.py:33-35);
+ *  box_mult  : decode multiplier, YOLOv3 32,32,16 (YOLOv3.py:346-348),
+ *              YOLOv2 32 (YOLOv2.py:191);
+ *  gt_rate   : ground-truth normalisation rate in the loss, YOLOv3 32,16,8
+ *              (YOLOv3.py:118-120), YOLOv2 32 (YOLOv2.py:106). */
+typedef struct yh_head_config {
+    int32_t num_scales;
+    int32_t num_priors;
+    int32_t num_classes;
+    int32_t grid_h[YH_MAX_SCALES];
+    int32_t grid_w[YH_MAX_SCALES];
+    float box_mult[YH_MAX_SCALES];
+    float gt_rate[YH_MAX_SCALES];
+    float prior_hw[YH_MAX_SCALES][YH_MAX_PRIORS][2];
+} yh_head_config;
+
+int yh_version(void);
+const char *yh_last_error(void);
+
+/* Number of visible HIP devices (host out).  YH_ERR_NO_DEVICE when the HIP
+ * runtime reports none: there is no CPU fallback. */
+int yh_device_count(int32_t *count);
+
+/* N = sum_s H_s * W_s * P (host out). */
+int yh_boxes_per_image(const yh_head_config *cfg, int64_t *n);
+
+/* Decode of every box: replaces YOLOv3.py:338-350 / YOLOv2.py:183-192, applied
+ * to every image of the batch.
+ *   boxes [B][N][4]; conf [B][N][C] = sigmoid(class) * sigmoid(obj), may be NULL. */
+int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float *boxes, float *conf, void *stream);
+
+/* Workspace size (host out) for yh_detect / yh_nms with these bounds. */
+int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
+                              int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);
+
+/* test_one_image's graph from the head tensors to detection_pred, for every
+ * image of the batch: replaces YOLOv3.py:320-368 / YOLOv2.py:183-210 (decode,
+ * conf >= score_threshold filter, per-class tf.image.non_max_suppression,
+ * gather, concat).  The confidence matrix is never materialised.
+ *   max_candidates : capacity for (box, class) pairs passing the score filter,
+ *                    per image; exceeding it sets YH_STATUS_CANDIDATE_OVERFLOW;
+ *   out_count   [B]                       detections K_b of image b;
+ *   out_scores  [B][C*nms_max_boxes]      first K_b valid; classes ascending,
+ *   out_boxes   [B][C*nms_max_boxes][4]   selection order inside a class
+ *   out_class   [B][C*nms_max_boxes]      (YOLOv3.py:362-367);
+ *   out_index   [B][C*nms_max_boxes]      box row n of each detection;
+ *   out_class_candidates [B][C]           per-class count after the score
+ *                                         filter (YOLOv3.py:356); may be NULL;
+ *   status      [1]                       device status word, zeroed by the call.
+ * Equal scores inside a class are taken in ascending box row. */
+int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+              int32_t max_candidates, void *workspace, size_t workspace_bytes,
+              int32_t *out_count, float *out_scores, float *out_boxes,
+              int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+              int32_t *status, void *stream);
+
+/* The same pipeline entered after the decode: replaces YOLOv3.py:351-368 /
+ * YOLOv2.py:193-210 on caller-supplied boxes [B][N][4] and conf [B][N][C].
+ * Workspace: yh_nms_workspace_bytes. */
+int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
+                           int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);
+int yh_nms(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
+           const float *boxes, const float *conf,
+           float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+           int32_t max_candidates, void *workspace, size_t workspace_bytes,
+           int32_t *out_count, float *out_scores, float *out_boxes,
+           int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+           int32_t *status, void *stream);
+
+/* Training loss of the batch up to the per-image values: replaces
+ * YOLOv3.py:117-310 / YOLOv2.py:105-173 (GT normalisation, best-prior and
+ * scale assignment, coordinate / class / object sums, the IoU ignore mask and
+ * the no-object sum).
+ *   ground_truth [B][pad][5]  (yc, xc, h, w, class) in pixels, -1 padded
+ *                             (utils/image_augmentor.py:205-244);
+ *   loss_scales (host) [4]    coord, noobj, obj, class (config order);
+ *   ignore_threshold          0.5 (YOLOv3.py:301) or 0.6 (YOLOv2.py:171);
+ *   normalize_by_num_gt       1: divide by the GT count (YOLOv3.py:308-309),
+ *                             0: do not (YOLOv2.py:172);
+ *   loss_per_image [B]; loss_parts [B][4] = coord, class, obj, noobj sums, may
+ *   be NULL; iou_max [B][N] = ignore-mask IoU maximum of every box (NaN in
+ *   cells holding a GT centre), may be NULL; loss_sum [1] = sum over the
+ *   batch's images (the value a data-parallel caller all-reduces before
+ *   dividing by the global batch, YOLOv3.py:311). */
+int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pad, size_t *bytes);
+int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+            int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+            int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+            float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOHEAD_H */

@@ -1,0 +1,480 @@
+// extern "C" boundary of libyolohead: argument checks, workspace carving and
+// kernel sequencing.  Declarations and the reference regions each entry point
+// replaces: include/yolohead.h.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include "yh_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail(YH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_config(const yh_head_config *cfg)
+{
+    if (!cfg) return fail(YH_ERR_INVALID_ARG, "cfg is null");
+    if (cfg->num_scales < 1 || cfg->num_scales > YH_MAX_SCALES)
+        return fail(YH_ERR_LIMIT, "num_scales %d outside [1, %d]", cfg->num_scales, YH_MAX_SCALES);
+    if (cfg->num_priors < 1 || cfg->num_priors > YH_MAX_PRIORS)
+        return fail(YH_ERR_LIMIT, "num_priors %d outside [1, %d]", cfg->num_priors, YH_MAX_PRIORS);
+    if (cfg->num_classes < 1 || cfg->num_classes > YH_MAX_CLASSES)
+        return fail(YH_ERR_LIMIT, "num_classes %d outside [1, %d]", cfg->num_classes, YH_MAX_CLASSES);
+    int64_t n = 0;
+    const int64_t K = cfg->num_classes + 5;
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        if (cfg->grid_h[s] < 1 || cfg->grid_w[s] < 1)
+            return fail(YH_ERR_INVALID_ARG, "grid %d is %d x %d", s, cfg->grid_h[s], cfg->grid_w[s]);
+        const int64_t rows = (int64_t)cfg->grid_h[s] * cfg->grid_w[s] * cfg->num_priors;
+        // the flat-index -> (row, channel) split uses a 32-bit multiply-high
+        if ((rows * K + K) * K >= (int64_t)1 << 32)
+            return fail(YH_ERR_LIMIT, "scale %d: rows * (C+5)^2 = %lld exceeds 2^32", s, (long long)(rows * K * K));
+        n += rows;
+    }
+    if (n > YH_MAX_BOXES_PER_IMAGE)
+        return fail(YH_ERR_LIMIT, "%lld boxes per image exceed %d", (long long)n, YH_MAX_BOXES_PER_IMAGE);
+    return YH_OK;
+}
+
+int64_t boxes_per_image(const yh_head_config *cfg)
+{
+    int64_t n = 0;
+    for (int s = 0; s < cfg->num_scales; ++s)
+        n += (int64_t)cfg->grid_h[s] * cfg->grid_w[s] * cfg->num_priors;
+    return n;
+}
+
+int check_heads(const yh_head_config *cfg, const float *const *heads)
+{
+    if (!heads) return fail(YH_ERR_INVALID_ARG, "heads is null");
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        if (!heads[s]) return fail(YH_ERR_INVALID_ARG, "heads[%d] is null", s);
+        if (reinterpret_cast<uintptr_t>(heads[s]) & 15u)
+            return fail(YH_ERR_ALIGN, "heads[%d] is not 16-byte aligned", s);
+    }
+    return YH_OK;
+}
+
+// Lower bound of the class logits that can still pass conf >= thr: conf <=
+// sigmoid(x) in fp32, so x must reach logit(thr) up to the error of the device
+// sigmoid; the margin below is orders of magnitude wider than that error.
+float prefilter_logit(float thr)
+{
+    if (!(thr > 0.0f)) return -std::numeric_limits<float>::infinity();   // thr <= 0 (or NaN): every finite logit goes to the exact test
+    if (thr > 1.0f) return std::numeric_limits<float>::infinity();
+    double t = (double)thr;
+    const double tmax = 1.0 - std::ldexp(1.0, -25);
+    if (t > tmax) t = tmax;
+    const double l = std::log(t / (1.0 - t));
+    return (float)(l - 1e-3 * (1.0 + std::fabs(l)));
+}
+
+struct DetectWs {
+    unsigned long long *cand, *seg_keys;
+    float *boxes;
+    int32_t *img_count, *seg_off, *seg_cnt, *kept_cnt, *kept_row;
+    float *kept_score;
+    size_t bytes;
+};
+
+// with_boxes: the workspace also holds the decoded boxes [B][N][4]
+DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, int64_t mb, bool with_boxes)
+{
+    DetectWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    char *p = static_cast<char *>(base);
+    const size_t o_cand = take((size_t)B * cap * 8), o_seg = take((size_t)B * cap * 8);
+    const size_t o_box = with_boxes ? take((size_t)B * N * 16) : 0;
+    const size_t o_img = take((size_t)B * 4), o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
+    const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
+    w.cand = reinterpret_cast<unsigned long long *>(p + o_cand);
+    w.seg_keys = reinterpret_cast<unsigned long long *>(p + o_seg);
+    w.boxes = with_boxes ? reinterpret_cast<float *>(p + o_box) : nullptr;
+    w.img_count = reinterpret_cast<int32_t *>(p + o_img);
+    w.seg_off = reinterpret_cast<int32_t *>(p + o_off);
+    w.seg_cnt = reinterpret_cast<int32_t *>(p + o_cnt);
+    w.kept_cnt = reinterpret_cast<int32_t *>(p + o_kc);
+    w.kept_row = reinterpret_cast<int32_t *>(p + o_kr);
+    w.kept_score = reinterpret_cast<float *>(p + o_ks);
+    w.bytes = off;
+    return w;
+}
+
+int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_cand, const void *ws,
+                   const void *oc, const void *os, const void *ob, const void *ocl, const void *oi, const void *status)
+{
+    if (batch < 0) return fail(YH_ERR_INVALID_ARG, "batch %d is negative", batch);
+    // tf.image.non_max_suppression requires iou_threshold in [0, 1]
+    if (!(iou_thr >= 0.0f && iou_thr <= 1.0f)) return fail(YH_ERR_INVALID_ARG, "iou_threshold %g outside [0, 1]", iou_thr);
+    if (max_boxes < 1 || max_boxes > YH_MAX_NMS_BOXES)
+        return fail(YH_ERR_LIMIT, "nms_max_boxes %d outside [1, %d]", max_boxes, YH_MAX_NMS_BOXES);
+    if (max_cand < 1) return fail(YH_ERR_INVALID_ARG, "max_candidates %d < 1", max_cand);
+    if (batch > 0 && (!ws || !oc || !os || !ob || !ocl || !oi || !status))
+        return fail(YH_ERR_INVALID_ARG, "null workspace, output or status pointer");
+    return YH_OK;
+}
+
+// Fills the per-scale stream descriptors and the block decomposition.
+uint32_t plan_stream(yh::StreamParams &p, int B)
+{
+    // total float4 slots; a workgroup takes a multiple of the slot granule, sized
+    // so that the launch has a few thousand workgroups (>> 256 CUs) while each
+    // flushes its candidates with a single atomic
+    uint64_t total_slots = 0;
+    for (int s = 0; s < p.S; ++s) total_slots += ((uint64_t)p.sc[s].span + 3) / 4 * (uint64_t)B;
+    uint64_t m = total_slots / 4096 / yh::kStreamSlotGranule;
+    if (m < 1) m = 1;
+    if (m > 8) m = 8;
+    p.chunk_slots = (uint32_t)(m * yh::kStreamSlotGranule);
+    uint32_t blocks = 0;
+    for (int s = 0; s < p.S; ++s) {
+        const uint64_t slots_img = ((uint64_t)p.sc[s].span + 6) / 4 + 1;   // any 16-byte phase of the image start
+        p.sc[s].chunks_per_img = (uint32_t)((slots_img + p.chunk_slots - 1) / p.chunk_slots);
+        p.sc[s].blk_begin = blocks;
+        blocks += p.sc[s].chunks_per_img * (uint32_t)B;
+    }
+    return blocks;
+}
+
+void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, const float *const *heads, int B)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.S = cfg->num_scales; p.B = B; p.C = cfg->num_classes; p.P = cfg->num_priors;
+    p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg);
+    p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
+    uint32_t row_base = 0;
+    for (int s = 0; s < p.S; ++s) {
+        yh::StreamScale &sc = p.sc[s];
+        sc.src = heads[s];
+        sc.rows_img = (uint32_t)cfg->grid_h[s] * cfg->grid_w[s] * cfg->num_priors;
+        sc.span = sc.rows_img * (uint32_t)p.K;
+        sc.grid_w = (uint32_t)cfg->grid_w[s];
+        sc.row_base = row_base;
+        sc.mult = cfg->box_mult[s];
+        std::memcpy(sc.prior_hw, cfg->prior_hw[s], sizeof(sc.prior_hw));
+        row_base += sc.rows_img;
+    }
+}
+
+int ensure_device()
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return fail(YH_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    return YH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yh_version(void) { return 100; }
+
+const char *yh_last_error(void) { return g_err; }
+
+int yh_device_count(int32_t *count)
+{
+    if (!count) return fail(YH_ERR_INVALID_ARG, "count is null");
+    *count = 0;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return fail(YH_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    *count = n;
+    return YH_OK;
+}
+
+int yh_boxes_per_image(const yh_head_config *cfg, int64_t *n)
+{
+    if (!n) return fail(YH_ERR_INVALID_ARG, "n is null");
+    const int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    *n = boxes_per_image(cfg);
+    return YH_OK;
+}
+
+int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float *boxes, float *conf, void *stream)
+{
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if (batch < 0) return fail(YH_ERR_INVALID_ARG, "batch %d is negative", batch);
+    if (batch == 0) return YH_OK;
+    if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
+    if (!boxes) return fail(YH_ERR_INVALID_ARG, "boxes is null");
+    if (reinterpret_cast<uintptr_t>(boxes) & 15u) return fail(YH_ERR_ALIGN, "boxes is not 16-byte aligned");
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    yh::StreamParams p;
+    fill_stream_from_config(p, cfg, heads, batch);
+    p.boxes = boxes;
+    p.conf = conf;
+    const uint32_t blocks = plan_stream(p, batch);
+    const hipError_t e = yh::launch_stream(p, yh::kModeFull, blocks, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "decode launch");
+    return YH_OK;
+}
+
+int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t max_candidates,
+                              int32_t nms_max_boxes, size_t *bytes)
+{
+    if (!bytes) return fail(YH_ERR_INVALID_ARG, "bytes is null");
+    const int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if (batch < 0 || max_candidates < 1 || nms_max_boxes < 1 || nms_max_boxes > YH_MAX_NMS_BOXES)
+        return fail(YH_ERR_INVALID_ARG, "bad batch / max_candidates / nms_max_boxes");
+    *bytes = carve_detect(nullptr, batch, boxes_per_image(cfg), cfg->num_classes, max_candidates,
+                          nms_max_boxes, true).bytes;
+    return YH_OK;
+}
+
+int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
+                           int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes)
+{
+    if (!bytes) return fail(YH_ERR_INVALID_ARG, "bytes is null");
+    if (batch < 0 || boxes_per_img < 1 || num_classes < 1 || max_candidates < 1 || nms_max_boxes < 1 ||
+        nms_max_boxes > YH_MAX_NMS_BOXES)
+        return fail(YH_ERR_INVALID_ARG, "bad size argument");
+    *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false).bytes;
+    return YH_OK;
+}
+
+static int run_nms_stage(const DetectWs &w, int32_t B, int32_t C, int32_t N, const float *boxes,
+                         float iou_thr, int32_t max_boxes, int32_t max_cand,
+                         int32_t *out_count, float *out_scores, float *out_boxes, int32_t *out_class,
+                         int32_t *out_index, int32_t *out_class_candidates, int32_t *status, hipStream_t st)
+{
+    yh::NmsParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.B = B; q.C = C; q.N = N; q.cand_cap = max_cand; q.max_boxes = max_boxes; q.iou_thr = iou_thr;
+    q.cand = w.cand; q.seg_keys = w.seg_keys; q.img_count = w.img_count;
+    q.seg_off = w.seg_off; q.seg_cnt = w.seg_cnt; q.kept_cnt = w.kept_cnt;
+    q.kept_row = w.kept_row; q.kept_score = w.kept_score; q.boxes = boxes;
+    q.out_count = out_count; q.out_scores = out_scores; q.out_boxes = out_boxes;
+    q.out_class = out_class; q.out_index = out_index; q.out_class_candidates = out_class_candidates;
+    q.status = status;
+    const hipError_t e = yh::launch_nms_pipeline(q, st);
+    if (e != hipSuccess) return hip_fail(e, "nms launch");
+    return YH_OK;
+}
+
+int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+              int32_t max_candidates, void *workspace, size_t workspace_bytes,
+              int32_t *out_count, float *out_scores, float *out_boxes,
+              int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+              int32_t *status, void *stream)
+{
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if ((rc = check_nms_args(batch, iou_threshold, nms_max_boxes, max_candidates, workspace, out_count,
+                             out_scores, out_boxes, out_class, out_index, status)) != YH_OK)
+        return rc;
+    if (batch == 0) return YH_OK;
+    if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (reinterpret_cast<uintptr_t>(out_boxes) & 15u))
+        return fail(YH_ERR_ALIGN, "workspace must be 256-byte and out_boxes 16-byte aligned");
+    const int64_t N = boxes_per_image(cfg);
+    const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true);
+    if (workspace_bytes < w.bytes)
+        return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    hipError_t e = hipMemsetAsync(w.img_count, 0, (size_t)batch * 4, st);
+    if (e != hipSuccess) return hip_fail(e, "memset counters");
+    e = hipMemsetAsync(status, 0, 4, st);
+    if (e != hipSuccess) return hip_fail(e, "memset status");
+
+    yh::StreamParams p;
+    fill_stream_from_config(p, cfg, heads, batch);
+    p.thr = score_threshold;
+    p.prefilter = prefilter_logit(score_threshold);
+    p.cand_cap = max_candidates;
+    p.cand = w.cand;
+    p.img_count = w.img_count;
+    p.boxes = w.boxes;
+    const uint32_t blocks = plan_stream(p, batch);
+    e = yh::launch_stream(p, yh::kModeDetect, blocks, st);
+    if (e != hipSuccess) return hip_fail(e, "detect stream launch");
+    return run_nms_stage(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold, nms_max_boxes,
+                         max_candidates, out_count, out_scores, out_boxes, out_class, out_index,
+                         out_class_candidates, status, st);
+}
+
+int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
+           const float *boxes, const float *conf,
+           float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+           int32_t max_candidates, void *workspace, size_t workspace_bytes,
+           int32_t *out_count, float *out_scores, float *out_boxes,
+           int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+           int32_t *status, void *stream)
+{
+    int rc = check_nms_args(batch, iou_threshold, nms_max_boxes, max_candidates, workspace, out_count,
+                            out_scores, out_boxes, out_class, out_index, status);
+    if (rc != YH_OK) return rc;
+    if (num_classes < 1 || num_classes > YH_MAX_CLASSES)
+        return fail(YH_ERR_LIMIT, "num_classes %d outside [1, %d]", num_classes, YH_MAX_CLASSES);
+    if (boxes_per_img < 1 || boxes_per_img > YH_MAX_BOXES_PER_IMAGE)
+        return fail(YH_ERR_LIMIT, "boxes_per_image %lld outside [1, %d]", (long long)boxes_per_img, YH_MAX_BOXES_PER_IMAGE);
+    if ((boxes_per_img * num_classes + num_classes) * (int64_t)num_classes >= (int64_t)1 << 32)
+        return fail(YH_ERR_LIMIT, "boxes_per_image * num_classes^2 exceeds 2^32");
+    if (batch == 0) return YH_OK;
+    if (!boxes || !conf) return fail(YH_ERR_INVALID_ARG, "boxes or conf is null");
+    if ((reinterpret_cast<uintptr_t>(boxes) & 15u) || (reinterpret_cast<uintptr_t>(conf) & 15u) ||
+        (reinterpret_cast<uintptr_t>(out_boxes) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(YH_ERR_ALIGN, "boxes / conf / out_boxes must be 16-byte and workspace 256-byte aligned");
+    const DetectWs w = carve_detect(workspace, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false);
+    if (workspace_bytes < w.bytes)
+        return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    hipError_t e = hipMemsetAsync(w.img_count, 0, (size_t)batch * 4, st);
+    if (e != hipSuccess) return hip_fail(e, "memset counters");
+    e = hipMemsetAsync(status, 0, 4, st);
+    if (e != hipSuccess) return hip_fail(e, "memset status");
+
+    // the confidence matrix is streamed as a one-scale "head" whose rows hold C channels
+    yh::StreamParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.S = 1; p.B = batch; p.C = num_classes; p.P = 1; p.K = num_classes; p.N = (int32_t)boxes_per_img;
+    p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
+    p.thr = score_threshold;
+    p.cand_cap = max_candidates;
+    p.cand = w.cand;
+    p.img_count = w.img_count;
+    p.sc[0].src = conf;
+    p.sc[0].rows_img = (uint32_t)boxes_per_img;
+    p.sc[0].span = (uint32_t)(boxes_per_img * num_classes);
+    p.sc[0].grid_w = 1;
+    const uint32_t blocks = plan_stream(p, batch);
+    e = yh::launch_stream(p, yh::kModeConf, blocks, st);
+    if (e != hipSuccess) return hip_fail(e, "conf stream launch");
+    return run_nms_stage(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold, nms_max_boxes,
+                         max_candidates, out_count, out_scores, out_boxes, out_class, out_index,
+                         out_class_candidates, status, st);
+}
+
+static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batch, int32_t pad)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.S = cfg->num_scales; p.B = batch; p.C = cfg->num_classes; p.P = cfg->num_priors;
+    p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg); p.pad = pad;
+    uint32_t blk = 0, row_base = 0;
+    for (int s = 0; s < p.S; ++s) {
+        yh::LossScale &sc = p.sc[s];
+        sc.H = cfg->grid_h[s]; sc.W = cfg->grid_w[s];
+        sc.rows_img = (uint32_t)sc.H * sc.W * cfg->num_priors;
+        sc.row_base = row_base;
+        sc.blk_begin = blk;
+        sc.gt_rate = cfg->gt_rate[s];
+        std::memcpy(sc.prior_hw, cfg->prior_hw[s], sizeof(sc.prior_hw));
+        blk += (sc.rows_img + yh::kLossNegThreads - 1) / yh::kLossNegThreads;
+        row_base += sc.rows_img;
+    }
+    p.blocks_per_img = (int32_t)blk;
+    p.pos_blocks = (pad + yh::kLossPosGtPerBlock - 1) / yh::kLossPosGtPerBlock;
+    if (p.pos_blocks < 1) p.pos_blocks = 1;
+}
+
+struct LossWs { float *neg, *pos; int32_t *gcount; size_t bytes; };
+
+static LossWs carve_loss(void *base, const yh::LossParams &p)
+{
+    LossWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    char *c = static_cast<char *>(base);
+    const size_t o_neg = take((size_t)p.B * p.blocks_per_img * 4);
+    const size_t o_pos = take((size_t)p.B * p.pos_blocks * 3 * 4);
+    const size_t o_g = take((size_t)p.B * 4);
+    w.neg = reinterpret_cast<float *>(c + o_neg);
+    w.pos = reinterpret_cast<float *>(c + o_pos);
+    w.gcount = reinterpret_cast<int32_t *>(c + o_g);
+    w.bytes = off;
+    return w;
+}
+
+static int check_loss_sizes(const yh_head_config *cfg, int32_t batch, int32_t pad)
+{
+    if (batch < 0) return fail(YH_ERR_INVALID_ARG, "batch %d is negative", batch);
+    if (pad < 1 || pad > 2048) return fail(YH_ERR_LIMIT, "pad %d outside [1, 2048]", pad);
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        if (!(cfg->gt_rate[s] > 0.0f)) return fail(YH_ERR_INVALID_ARG, "gt_rate[%d] must be positive", s);
+        if ((int64_t)cfg->grid_h[s] * cfg->grid_w[s] > (1 << 18))
+            return fail(YH_ERR_LIMIT, "grid %d has more than 2^18 cells", s);
+    }
+    return YH_OK;
+}
+
+int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pad, size_t *bytes)
+{
+    if (!bytes) return fail(YH_ERR_INVALID_ARG, "bytes is null");
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if ((rc = check_loss_sizes(cfg, batch, pad)) != YH_OK) return rc;
+    yh::LossParams p;
+    plan_loss(p, cfg, batch, pad);
+    *bytes = carve_loss(nullptr, p).bytes;
+    return YH_OK;
+}
+
+int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+            int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+            int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+            float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+            void *stream)
+{
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if ((rc = check_loss_sizes(cfg, batch, pad)) != YH_OK) return rc;
+    if (!loss_scales) return fail(YH_ERR_INVALID_ARG, "loss_scales is null");
+    if (batch == 0) return YH_OK;
+    if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
+    if (!ground_truth || !workspace || !loss_per_image)
+        return fail(YH_ERR_INVALID_ARG, "null ground_truth, workspace or loss_per_image");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail(YH_ERR_ALIGN, "workspace is not 256-byte aligned");
+    yh::LossParams p;
+    plan_loss(p, cfg, batch, pad);
+    const LossWs w = carve_loss(workspace, p);
+    if (workspace_bytes < w.bytes)
+        return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    for (int s = 0; s < p.S; ++s) p.sc[s].head = heads[s];
+    p.w_coord = loss_scales[0]; p.w_noobj = loss_scales[1]; p.w_obj = loss_scales[2]; p.w_class = loss_scales[3];
+    p.ignore_thr = ignore_threshold;
+    p.normalize = normalize_by_num_gt ? 1 : 0;
+    p.gt = ground_truth;
+    p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount;
+    p.loss_per_image = loss_per_image; p.loss_parts = loss_parts; p.iou_max = iou_max; p.loss_sum = loss_sum;
+    const hipError_t e = yh::launch_loss(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "loss launch");
+    return YH_OK;
+}
+
+}  // extern "C"

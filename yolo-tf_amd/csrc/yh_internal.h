@@ -1,0 +1,139 @@
+// Internal declarations shared by the kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "yolohead.h"
+
+namespace yh {
+
+// ---- candidate key -------------------------------------------------------
+// key64 = class(12) | ~orderable(score)(32) | box row(20): ascending key order
+// is class ascending, score descending, box row ascending.
+constexpr int kRowBits = 20;
+constexpr int kScoreShift = kRowBits;
+constexpr int kClassShift = 52;
+
+__host__ __device__ inline uint32_t orderable_bits(uint32_t u)
+{
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending with the float order
+}
+__host__ __device__ inline uint32_t orderable_bits_inv(uint32_t o)
+{
+    return (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+}
+__device__ inline unsigned long long make_key(int cls, float score, int row)
+{
+    const uint32_t part = ~orderable_bits(__float_as_uint(score));
+    return ((unsigned long long)(uint32_t)cls << kClassShift) |
+           ((unsigned long long)part << kScoreShift) | (unsigned long long)(uint32_t)row;
+}
+__device__ inline int key_class(unsigned long long k) { return (int)(k >> kClassShift); }
+__device__ inline int key_row(unsigned long long k) { return (int)(k & ((1u << kRowBits) - 1u)); }
+__device__ inline float key_score(unsigned long long k)
+{
+    const uint32_t part = (uint32_t)(k >> kScoreShift);
+    return __uint_as_float(orderable_bits_inv(~part));
+}
+
+// ---- arithmetic shared by every kernel (fp32, no contraction) -----------
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
+__device__ __forceinline__ float sigmoid_ce(float x, float z)
+{
+    return (fmaxf(x, 0.0f) - x * z) + log1pf(expf(-fabsf(x)));
+}
+
+// ---- streaming pass (decode / threshold / compaction) --------------------
+struct StreamScale {
+    const float *src;       // head [B][rows_img][K] or conf [B][rows_img][K]
+    uint32_t rows_img;      // rows of one image at this scale
+    uint32_t span;          // rows_img * K floats
+    uint32_t grid_w;
+    uint32_t row_base;      // first box row of this scale inside an image
+    uint32_t blk_begin;     // first block of this scale
+    uint32_t chunks_per_img;
+    float mult;
+    float prior_hw[YH_MAX_PRIORS][2];
+};
+
+struct StreamParams {
+    int32_t S, B, C, P, K, N;
+    uint32_t magic_k;       // floor(2^32 / K) + 1
+    uint32_t chunk_slots;   // float4 slots per block (multiple of 256 * kUnroll)
+    float thr;              // score threshold
+    float prefilter;        // logits below this cannot reach thr
+    int32_t cand_cap;
+    unsigned long long *cand;   // [B][cand_cap]
+    int32_t *img_count;         // [B]
+    float *boxes;               // [B][N][4]
+    float *conf;                // [B][N][C] (full decode only, may be null)
+    StreamScale sc[YH_MAX_SCALES];
+};
+
+constexpr uint32_t kStreamSlotGranule = 256 * 8;   // slots one workgroup reads per loop trip
+
+enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
+
+hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t st);
+
+// ---- candidates -> detections --------------------------------------------
+struct NmsParams {
+    int32_t B, C, N;
+    int32_t cand_cap;
+    int32_t max_boxes;
+    float iou_thr;
+    const unsigned long long *cand;    // [B][cand_cap] unordered
+    unsigned long long *seg_keys;      // [B][cand_cap] binned by class, then sorted
+    const int32_t *img_count;          // [B]
+    int32_t *seg_off;                  // [B][C]
+    int32_t *seg_cnt;                  // [B][C]
+    int32_t *kept_cnt;                 // [B][C]
+    int32_t *kept_row;                 // [B][C][max_boxes]
+    float *kept_score;                 // [B][C][max_boxes]
+    const float *boxes;                // [B][N][4]
+    int32_t *out_count;                // [B]
+    float *out_scores;                 // [B][C*max_boxes]
+    float *out_boxes;                  // [B][C*max_boxes][4]
+    int32_t *out_class;
+    int32_t *out_index;
+    int32_t *out_class_candidates;     // [B][C] or null
+    int32_t *status;
+};
+
+hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
+
+// ---- loss ------------------------------------------------------------------
+struct LossScale {
+    const float *head;
+    int32_t H, W;
+    uint32_t rows_img;
+    uint32_t row_base;
+    uint32_t blk_begin;     // first negative-branch block of this scale inside an image
+    float gt_rate;
+    float prior_hw[YH_MAX_PRIORS][2];
+};
+
+struct LossParams {
+    int32_t S, B, C, P, K, N, pad;
+    int32_t blocks_per_img;       // negative-branch blocks per image (all scales)
+    float w_coord, w_noobj, w_obj, w_class;
+    float ignore_thr;
+    int32_t normalize;
+    const float *gt;              // [B][pad][5]
+    float *neg_partial;           // [B][blocks_per_img]
+    float *pos_partial;           // [B][pos_blocks][3]
+    int32_t pos_blocks;
+    int32_t *gcount;              // [B] ground-truth rows per image
+    float *loss_per_image;        // [B]
+    float *loss_parts;            // [B][4] or null
+    float *iou_max;               // [B][N] or null
+    float *loss_sum;              // [1]
+    LossScale sc[YH_MAX_SCALES];
+};
+
+hipError_t launch_loss(const LossParams &p, hipStream_t st);
+
+constexpr int kLossNegThreads = 256;
+constexpr int kLossPosGtPerBlock = 4;   // one wave per ground-truth box
+
+}  // namespace yh

@@ -1,0 +1,305 @@
+// Training loss of the detection head: ground-truth normalisation, best-prior
+// and scale assignment with the coordinate / class / object sums (positive
+// branch), and the IoU ignore mask with the no-object sum (negative branch).
+// Replaces YOLOv3.py:117-310 / YOLOv2.py:105-173.
+//
+// The reference materialises [A][G][P][2] broadcast tiles for the ignore mask;
+// here a lane owns one (cell, prior) box, the image's ground-truth corners sit
+// in LDS and are read as broadcasts, and the only HBM traffic of the negative
+// branch is the objectness logit of every row.  IoU uses + - * / min max only,
+// in the reference's operation order, compiled without contraction, so the
+// mask decisions are the same bits a CPU evaluation produces.
+#include "yh_internal.h"
+
+namespace yh {
+
+constexpr int kPosThreads = 64 * kLossPosGtPerBlock;
+
+// _get_normlized_gn's slice (YOLOv3.py:437): the first index of the minimum of
+// column 0 of gt [pad][5].  Block-wide; result broadcast through *out.
+__device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx, int nthreads)
+{
+    const int tid = threadIdx.x;
+    float bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < pad; j += nthreads) {
+        const float v = gt[j * 5];
+        if (v < bv) { bv = v; bi = j; }          // strict: keeps the first index per thread
+    }
+    // wave reduce on (value, index), lower index wins ties
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(bv, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    float fv = s_val[0];
+    int fi = s_idx[0];
+    for (int w = 1; w < nthreads / 64; ++w) {
+        const float ov = s_val[w];
+        const int oi = s_idx[w];
+        if (ov < fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
+    }
+    __syncthreads();
+    return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
+}
+
+// ---------------------------------------------------------------- negative
+// grid = B * blocks_per_img; a block owns 256 consecutive box rows of one scale
+// of one image.  Dynamic LDS: 5 * pad floats (GT corners + area at this scale)
+// followed by the cell-occupancy bitmap of the scale.
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_neg(const LossParams p)
+{
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ float s_val[kLossNegThreads / 64];
+    __shared__ int s_idx[kLossNegThreads / 64];
+    float *s_gt = reinterpret_cast<float *>(s_raw);                 // [pad][5]: y1 x1 y2 x2 area
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_raw + (size_t)p.pad * 5 * sizeof(float));
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / p.blocks_per_img;
+    const uint32_t r = blockIdx.x - (uint32_t)b * p.blocks_per_img;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && r >= p.sc[i].blk_begin) s = i;
+    const LossScale &sc = p.sc[s];
+    const uint32_t row = (r - sc.blk_begin) * kLossNegThreads + tid;
+    const int C = p.C, K = p.K, P = p.P, H = sc.H, W = sc.W;
+    const float *gt = p.gt + (long long)b * p.pad * 5;
+
+    // objectness logit first: its latency hides behind the prologue
+    float obj = 0.0f;
+    const bool in_range = row < sc.rows_img;
+    if (in_range) obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
+
+    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kLossNegThreads);
+    const int occ_words = (H * W + 31) >> 5;
+    for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
+    __syncthreads();
+    const float rate = sc.gt_rate;
+    for (int g = tid; g < G; g += kLossNegThreads) {
+        const float gy = gt[g * 5 + 0] / rate, gx = gt[g * 5 + 1] / rate;
+        const float gh = gt[g * 5 + 2] / rate, gw = gt[g * 5 + 3] / rate;
+        const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
+        const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
+        s_gt[g * 5 + 0] = y1; s_gt[g * 5 + 1] = x1; s_gt[g * 5 + 2] = y2; s_gt[g * 5 + 3] = x2;
+        s_gt[g * 5 + 4] = (y2 - y1) * (x2 - x1);
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (cy >= 0 && cy < H && cx >= 0 && cx < W) {
+            const int cell = cy * W + cx;
+            atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
+        }
+    }
+    __syncthreads();
+
+    float contrib = 0.0f;
+    if (in_range) {
+        const uint32_t cell = row / (uint32_t)P;
+        const uint32_t pi = row - cell * (uint32_t)P;
+        const uint32_t cy = cell / (uint32_t)W, cx = cell - cy * (uint32_t)W;
+        const bool occupied = (s_occ[cell >> 5] >> (cell & 31)) & 1u;
+        float m = __builtin_nanf("");
+        if (!occupied) {
+            // YOLOv3.py:246-257: L = a_yx - a_hw/2 and U = a_yx + a_hw/2 are then used
+            // as (centre, size): corners L - U/2 and L + U/2.
+            const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
+            const float ah = sc.prior_hw[pi][0], aw = sc.prior_hw[pi][1];
+            const float ly = ay - ah / 2.0f, lx = ax - aw / 2.0f;
+            const float uy = ay + ah / 2.0f, ux = ax + aw / 2.0f;
+            const float by1 = ly - uy / 2.0f, bx1 = lx - ux / 2.0f;
+            const float by2 = ly + uy / 2.0f, bx2 = lx + ux / 2.0f;
+            const float aarea = (by2 - by1) * (bx2 - bx1);
+            m = -INFINITY;
+            bool any_nan = false;
+            for (int g = 0; g < G; ++g) {
+                const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
+                const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
+                const float garea = s_gt[g * 5 + 4];
+                // intersection NOT clamped at zero (YOLOv3.py:286)
+                const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                const float iou = inter / ((aarea + garea) - inter);
+                if (iou != iou) any_nan = true;
+                else if (iou > m) m = iou;
+            }
+            if (any_nan) m = __builtin_nanf("");
+            if (m <= p.ignore_thr) contrib = sigmoid_ce(obj, 0.0f);
+        }
+        if (p.iou_max) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
+    }
+
+    // block sum, fixed order
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+    if ((tid & 63) == 0) s_val[tid >> 6] = contrib;
+    __syncthreads();
+    if (tid == 0) {
+        float acc = s_val[0];
+        for (int w = 1; w < kLossNegThreads / 64; ++w) acc += s_val[w];
+        p.neg_partial[(long long)b * p.blocks_per_img + r] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- positive
+// grid = B * pos_blocks; one wavefront per ground-truth row.  Every lane
+// evaluates the (cheap) assignment redundantly, then the lanes split the K
+// channels of the assigned head row.
+__global__ __launch_bounds__(kPosThreads) void k_loss_pos(const LossParams p)
+{
+    __shared__ float s_val[kPosThreads / 64];
+    __shared__ int s_idx[kPosThreads / 64];
+    __shared__ float s_part[kPosThreads / 64][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.pos_blocks;
+    const int blk = blockIdx.x - b * p.pos_blocks;
+    const float *gt = p.gt + (long long)b * p.pad * 5;
+    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+    if (blk == 0 && tid == 0) p.gcount[b] = G;
+
+    const int g = blk * kLossPosGtPerBlock + wave;
+    float coord = 0.0f, cls = 0.0f, obj = 0.0f;
+    if (g < G) {
+        const int S = p.S, P = p.P, C = p.C, K = p.K;
+        const float y = gt[g * 5 + 0], x = gt[g * 5 + 1], h = gt[g * 5 + 2], w = gt[g * 5 + 3];
+        const int label = (int)gt[g * 5 + 4];                 // tf.cast(float -> int32) truncates
+        float best_iou[YH_MAX_SCALES];
+        int best_p[YH_MAX_SCALES];
+#pragma unroll
+        for (int s = 0; s < YH_MAX_SCALES; ++s) {
+            best_iou[s] = 0.0f; best_p[s] = 0;
+            if (s < S) {
+                const float rate = p.sc[s].gt_rate;
+                const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
+                const float ay = floorf(gy) + 0.5f, ax = floorf(gx) + 0.5f;
+                const float gy1 = gy - gh / 2.0f, gx1 = gx - gw / 2.0f;
+                const float gy2 = gy + gh / 2.0f, gx2 = gx + gw / 2.0f;
+                const float garea = (gy2 - gy1) * (gx2 - gx1);
+                for (int q = 0; q < P; ++q) {
+                    const float ah = p.sc[s].prior_hw[q][0], aw = p.sc[s].prior_hw[q][1];
+                    const float ay1 = ay - ah / 2.0f, ax1 = ax - aw / 2.0f;
+                    const float ay2 = ay + ah / 2.0f, ax2 = ax + aw / 2.0f;
+                    // YOLOv3.py:159-177: intersection not clamped, anchor area = prod(hw)
+                    const float inter = (fminf(gy2, ay2) - fmaxf(gy1, ay1)) * (fminf(gx2, ax2) - fmaxf(gx1, ax1));
+                    const float iou = inter / ((ah * aw + garea) - inter);
+                    if (q == 0 || iou > best_iou[s]) { best_iou[s] = iou; best_p[s] = q; }   // argmax: first maximum
+                }
+            }
+        }
+        // YOLOv3.py:185-189: scale s < S-1 takes the GT when it beats every other scale
+        // strictly; everything else goes to the last scale.
+        int ssel = S - 1;
+        bool found = false;
+#pragma unroll
+        for (int s = 0; s < YH_MAX_SCALES; ++s) {
+            if (s < S - 1 && !found) {
+                bool wins = true;
+#pragma unroll
+                for (int t = 0; t < YH_MAX_SCALES; ++t)
+                    if (t < S && t != s && !(best_iou[s] > best_iou[t])) wins = false;
+                if (wins) { ssel = s; found = true; }
+            }
+        }
+        int psel = 0;
+#pragma unroll
+        for (int s = 0; s < YH_MAX_SCALES; ++s) if (s == ssel) psel = best_p[s];
+        const LossScale &sc = p.sc[ssel];
+        const float rate = sc.gt_rate;
+        const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (cy >= 0 && cy < sc.H && cx >= 0 && cx < sc.W) {
+            const float *rowp = sc.head + ((((long long)b * sc.H + cy) * sc.W + cx) * P + psel) * K;
+            for (int k = lane; k < K; k += 64) {
+                const float v = rowp[k];
+                if (k < C) {
+                    cls += sigmoid_ce(v, k == label ? 1.0f : 0.0f);
+                } else if (k == C) {
+                    coord += sigmoid_ce(v, gy - floorf(gy));
+                } else if (k == C + 1) {
+                    coord += sigmoid_ce(v, gx - floorf(gx));
+                } else if (k == C + 2) {
+                    const float d = v - logf(gh / sc.prior_hw[psel][0]);
+                    coord += 0.5f * (d * d);
+                } else if (k == C + 3) {
+                    const float d = v - logf(gw / sc.prior_hw[psel][1]);
+                    coord += 0.5f * (d * d);
+                } else {
+                    obj += sigmoid_ce(v, 1.0f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        coord += __shfl_xor(coord, d, 64);
+        cls += __shfl_xor(cls, d, 64);
+        obj += __shfl_xor(obj, d, 64);
+    }
+    if (lane == 0) { s_part[wave][0] = coord; s_part[wave][1] = cls; s_part[wave][2] = obj; }
+    __syncthreads();
+    if (tid < 3) {
+        float acc = s_part[0][tid];
+        for (int w2 = 1; w2 < kPosThreads / 64; ++w2) acc += s_part[w2][tid];
+        p.pos_partial[((long long)b * p.pos_blocks + blk) * 3 + tid] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- finalize
+// One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
+// the batch sum in a fixed order.
+__global__ __launch_bounds__(256) void k_loss_finalize(const LossParams p)
+{
+    __shared__ double s_sum[256];
+    const int tid = threadIdx.x;
+    double local = 0.0;
+    for (int b = tid; b < p.B; b += 256) {
+        double coord = 0.0, cls = 0.0, obj = 0.0, noobj = 0.0;
+        const float *pp = p.pos_partial + (long long)b * p.pos_blocks * 3;
+        for (int i = 0; i < p.pos_blocks; ++i) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
+        const float *np_ = p.neg_partial + (long long)b * p.blocks_per_img;
+        for (int i = 0; i < p.blocks_per_img; ++i) noobj += np_[i];
+        const float fc = (float)coord, fk = (float)cls, fo = (float)obj, fn = (float)noobj;
+        float pos = (p.w_coord * fc + p.w_class * fk) + p.w_obj * fo;
+        float neg = p.w_noobj * fn;
+        if (p.normalize) {
+            const float gf = (float)p.gcount[b];
+            pos = pos / gf; neg = neg / gf;
+        }
+        const float li = pos + neg;
+        p.loss_per_image[b] = li;
+        if (p.loss_parts) {
+            p.loss_parts[b * 4 + 0] = fc; p.loss_parts[b * 4 + 1] = fk;
+            p.loss_parts[b * 4 + 2] = fo; p.loss_parts[b * 4 + 3] = fn;
+        }
+        local += (double)li;
+    }
+    s_sum[tid] = local;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) s_sum[tid] += s_sum[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0 && p.loss_sum) *p.loss_sum = (float)s_sum[0];
+}
+
+hipError_t launch_loss(const LossParams &p, hipStream_t stm)
+{
+    if (p.B == 0) return hipSuccess;
+    int occ_words = 0;
+    for (int s = 0; s < p.S; ++s) {
+        const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
+        if (w > occ_words) occ_words = w;
+    }
+    const size_t lds = (size_t)p.pad * 5 * sizeof(float) + (size_t)occ_words * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_loss_pos, dim3((uint32_t)p.B * p.pos_blocks), dim3(kPosThreads), 0, stm, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss_neg, dim3((uint32_t)p.B * p.blocks_per_img), dim3(kLossNegThreads), lds, stm, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, stm, p);
+    return hipGetLastError();
+}
+
+}  // namespace yh

@@ -1,0 +1,257 @@
+"""Host side of the detection-head path: owns device buffers (through torch),
+describes the head geometry and calls libyolohead through ctypes.
+
+torch is plumbing here (device memory, streams); every computation happens in
+the HIP kernels behind the C ABI.  Without the shared library or without a HIP
+device these functions raise; nothing falls back to the CPU."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _abi
+
+
+def make_config(grids, priors, box_mult, gt_rate, num_classes):
+    """Builds struct yh_head_config.  grids: [(H, W)] per scale; priors: per
+    scale [P][2] (h, w) in grid units."""
+    S = len(grids)
+    if not (len(priors) == len(box_mult) == len(gt_rate) == S):
+        raise ValueError('grids, priors, box_mult and gt_rate must have one entry per scale')
+    if S < 1 or S > _abi.YH_MAX_SCALES:
+        raise ValueError('1..%d scales supported' % _abi.YH_MAX_SCALES)
+    P = len(priors[0])
+    if P < 1 or P > _abi.YH_MAX_PRIORS:
+        raise ValueError('1..%d priors per scale supported' % _abi.YH_MAX_PRIORS)
+    cfg = _abi.HeadConfig()
+    cfg.num_scales = S
+    cfg.num_priors = P
+    cfg.num_classes = int(num_classes)
+    for s in range(S):
+        pr = np.asarray(priors[s], dtype=np.float32).reshape(-1, 2)
+        if pr.shape[0] != P:
+            raise ValueError('every scale must have the same number of priors')
+        cfg.grid_h[s] = int(grids[s][0])
+        cfg.grid_w[s] = int(grids[s][1])
+        cfg.box_mult[s] = float(box_mult[s])
+        cfg.gt_rate[s] = float(gt_rate[s])
+        for p in range(P):
+            cfg.prior_hw[s][p][0] = float(pr[p, 0])
+            cfg.prior_hw[s][p][1] = float(pr[p, 1])
+    return cfg
+
+
+class Detections:
+    """Device-resident result of DetectionHead.detect / .nms for a batch."""
+
+    def __init__(self, count, scores, boxes, class_id, index, class_candidates, status, rerun):
+        self.count = count                  # [B] int32
+        self.scores = scores                # [B, C*max_boxes] float32, first count[b] valid
+        self.boxes = boxes                  # [B, C*max_boxes, 4] float32 (y1, x1, y2, x2)
+        self.class_id = class_id            # [B, C*max_boxes] int32
+        self.index = index                  # [B, C*max_boxes] int32: box row of each detection
+        self.class_candidates = class_candidates   # [B, C] int32 or None
+        self.status = status                # [1] int32 device status word
+        self._rerun = rerun
+
+    def overflowed(self):
+        """Synchronises and reports whether an image exceeded max_candidates."""
+        return bool(int(self.status.item()) & _abi.YH_STATUS_CANDIDATE_OVERFLOW)
+
+    def resolved(self):
+        """Synchronises; if the candidate capacity overflowed, reruns with the
+        worst-case capacity and returns the rerun's result."""
+        if self.overflowed():
+            if self._rerun is None:
+                raise RuntimeError('candidate capacity overflow; raise max_candidates')
+            return self._rerun()
+        return self
+
+    def per_image(self):
+        """[(scores [K], bbox [K,4], class_id [K], index [K])] as NumPy arrays,
+        the reference's detection_pred layout (YOLOv3.py:365-368) plus the box row."""
+        r = self.resolved()
+        count = r.count.cpu().numpy()
+        scores = r.scores.cpu().numpy(); boxes = r.boxes.cpu().numpy()
+        cls = r.class_id.cpu().numpy(); idx = r.index.cpu().numpy()
+        out = []
+        for b in range(count.shape[0]):
+            k = int(count[b])
+            out.append((scores[b, :k].copy(), boxes[b, :k].copy(), cls[b, :k].copy(), idx[b, :k].copy()))
+        return out
+
+
+class DetectionHead:
+    """The reference's head geometry (priors, multipliers, rates) bound to the
+    HIP kernels.  heads are NHWC float32 CUDA tensors [B, H, W, P*(C+5)]."""
+
+    def __init__(self, num_classes, priors, box_mult, gt_rate):
+        self.num_classes = int(num_classes)
+        self.priors = [np.asarray(p, dtype=np.float32).reshape(-1, 2) for p in priors]
+        self.num_priors = self.priors[0].shape[0]
+        self.box_mult = [float(m) for m in box_mult]
+        self.gt_rate = [float(r) for r in gt_rate]
+        self._ws = {}
+
+    # ------------------------------------------------------------ helpers
+    def _check_heads(self, heads):
+        if len(heads) != len(self.priors):
+            raise ValueError('%d head tensors given, %d scales configured' % (len(heads), len(self.priors)))
+        K = self.num_priors * (self.num_classes + 5)
+        B = heads[0].shape[0]
+        dev = heads[0].device
+        out = []
+        for h in heads:
+            if not isinstance(h, torch.Tensor):
+                raise TypeError('heads must be torch tensors on a HIP device')
+            if h.device.type != 'cuda':
+                raise RuntimeError('head tensors must live on a HIP device (got %s); there is no CPU path' % h.device)
+            if h.dtype != torch.float32 or h.dim() != 4 or h.shape[3] != K or h.shape[0] != B or h.device != dev:
+                raise ValueError('every head must be float32 [B, H, W, %d] on one device' % K)
+            out.append(h.contiguous())
+        return out
+
+    def config_for(self, heads):
+        grids = [(int(h.shape[1]), int(h.shape[2])) for h in heads]
+        return make_config(grids, self.priors, self.box_mult, self.gt_rate, self.num_classes)
+
+    def boxes_per_image(self, heads):
+        return sum(int(h.shape[1]) * int(h.shape[2]) * self.num_priors for h in heads)
+
+    def _workspace(self, key, nbytes, device):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _stream(device):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    # ------------------------------------------------------------- decode
+    def decode(self, heads, want_conf=True):
+        """bbox [B,N,4] and confidence [B,N,C] of YOLOv3.py:338-350."""
+        lib = _abi.load()
+        heads = self._check_heads(heads)
+        cfg = self.config_for(heads)
+        B, N, C = heads[0].shape[0], self.boxes_per_image(heads), self.num_classes
+        dev = heads[0].device
+        boxes = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        conf = torch.empty((B, N, C), dtype=torch.float32, device=dev) if want_conf else None
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_decode(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
+                                     boxes.data_ptr(), conf.data_ptr() if want_conf else None, self._stream(dev)))
+        return boxes, conf
+
+    # ------------------------------------------------------------- detect
+    def default_max_candidates(self, N):
+        full = N * self.num_classes
+        return int(min(full, max(4096, full // 16)))
+
+    def _alloc_outputs(self, B, max_boxes, dev, want_class_candidates):
+        C = self.num_classes
+        cap = C * max_boxes
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+        scores = torch.empty((B, cap), dtype=torch.float32, device=dev)
+        boxes = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
+        cls = torch.empty((B, cap), dtype=torch.int32, device=dev)
+        idx = torch.empty((B, cap), dtype=torch.int32, device=dev)
+        cc = torch.empty((B, C), dtype=torch.int32, device=dev) if want_class_candidates else None
+        status = torch.empty((1,), dtype=torch.int32, device=dev)
+        return count, scores, boxes, cls, idx, cc, status
+
+    def detect(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates=None,
+               want_class_candidates=False, outputs=None):
+        """Decode + score filter + per-class NMS for every image (YOLOv3.py:320-368).
+        Enqueues on the current stream and returns device tensors; nothing
+        synchronises until the result is read."""
+        lib = _abi.load()
+        heads = self._check_heads(heads)
+        cfg = self.config_for(heads)
+        B, N = heads[0].shape[0], self.boxes_per_image(heads)
+        dev = heads[0].device
+        cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
+        nbytes = ctypes.c_size_t(0)
+        _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
+        ws = self._workspace(('detect', B, N, cap, int(max_boxes)), nbytes.value, dev)
+        if outputs is None:
+            outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
+        count, scores, boxes, cls, idx, cc, status = outputs
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_detect(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
+                                     float(score_threshold), float(iou_threshold), int(max_boxes), cap,
+                                     ws.data_ptr(), ws.numel(), count.data_ptr(), scores.data_ptr(),
+                                     boxes.data_ptr(), cls.data_ptr(), idx.data_ptr(),
+                                     cc.data_ptr() if cc is not None else None, status.data_ptr(),
+                                     self._stream(dev)))
+        full = N * self.num_classes
+        rerun = None
+        if cap < full:
+            rerun = lambda: self.detect(heads, score_threshold, iou_threshold, max_boxes, full,
+                                        want_class_candidates)
+        return Detections(count, scores, boxes, cls, idx, cc, status, rerun)
+
+    def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
+            want_class_candidates=False):
+        """Score filter + per-class NMS on decoded inputs (YOLOv3.py:351-368).
+        boxes [B,N,4], conf [B,N,C] float32 CUDA tensors."""
+        lib = _abi.load()
+        if boxes.device.type != 'cuda' or conf.device != boxes.device:
+            raise RuntimeError('boxes and conf must live on one HIP device; there is no CPU path')
+        boxes = boxes.contiguous(); conf = conf.contiguous()
+        B, N, C = conf.shape
+        if C != self.num_classes or boxes.shape != (B, N, 4):
+            raise ValueError('expected boxes [B,N,4] and conf [B,N,%d]' % self.num_classes)
+        dev = boxes.device
+        full = N * C
+        cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
+        nbytes = ctypes.c_size_t(0)
+        _abi.check(lib.yh_nms_workspace_bytes(B, N, C, cap, int(max_boxes), ctypes.byref(nbytes)))
+        ws = self._workspace(('nms', B, N, cap, int(max_boxes)), nbytes.value, dev)
+        count, scores, oboxes, cls, idx, cc, status = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_nms(B, N, C, boxes.data_ptr(), conf.data_ptr(), float(score_threshold),
+                                  float(iou_threshold), int(max_boxes), cap, ws.data_ptr(), ws.numel(),
+                                  count.data_ptr(), scores.data_ptr(), oboxes.data_ptr(), cls.data_ptr(),
+                                  idx.data_ptr(), cc.data_ptr() if cc is not None else None,
+                                  status.data_ptr(), self._stream(dev)))
+        rerun = None
+        if cap < full:
+            rerun = lambda: self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, full,
+                                     want_class_candidates)
+        return Detections(count, scores, oboxes, cls, idx, cc, status, rerun)
+
+    # --------------------------------------------------------------- loss
+    def loss(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+             ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False):
+        """Per-image training loss (YOLOv3.py:117-310 / YOLOv2.py:105-173).
+        ground_truth: [B, pad, 5] float32 CUDA tensor, -1 padded.
+        Returns dict(per_image [B], sum [1], parts [B,4] | None, iou_max [B,N] | None)."""
+        lib = _abi.load()
+        heads = self._check_heads(heads)
+        cfg = self.config_for(heads)
+        dev = heads[0].device
+        if ground_truth.device != dev:
+            raise RuntimeError('ground_truth must live on the heads\' device')
+        gt = ground_truth.to(torch.float32).contiguous()
+        B, N = heads[0].shape[0], self.boxes_per_image(heads)
+        if gt.dim() != 3 or gt.shape[0] != B or gt.shape[2] != 5:
+            raise ValueError('ground_truth must be [B, pad, 5]')
+        pad = int(gt.shape[1])
+        nbytes = ctypes.c_size_t(0)
+        _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
+        ws = self._workspace(('loss', B, N, pad), nbytes.value, dev)
+        per = torch.empty((B,), dtype=torch.float32, device=dev)
+        total = torch.empty((1,), dtype=torch.float32, device=dev)
+        parts = torch.empty((B, 4), dtype=torch.float32, device=dev) if want_parts else None
+        iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
+        scales = (ctypes.c_float * 4)(float(coord_scale), float(noobj_scale), float(obj_scale), float(class_scale))
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_loss(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
+                                   gt.data_ptr(), B, pad, scales, float(ignore_threshold),
+                                   1 if normalize_by_num_gt else 0, ws.data_ptr(), ws.numel(),
+                                   per.data_ptr(), parts.data_ptr() if want_parts else None,
+                                   iou.data_ptr() if want_iou_max else None, total.data_ptr(),
+                                   self._stream(dev)))
+        return dict(per_image=per, sum=total, parts=parts, iou_max=iou)

@@ -1,0 +1,47 @@
+"""Data parallelism of the path: images are sharded across ranks (one process
+per GPU) and the only exchange is the loss scalar.
+
+The reference is single-process; its batch semantics are reduce_mean over the
+images of the batch (YOLOv3.py:311, YOLOv2.py:174), reproduced here over the
+global batch with one all-reduce of (sum of per-image losses, image count)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous image range [begin, end) of `rank`; the first total % world
+    ranks take one extra image."""
+    base, extra = divmod(int(total), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT when WORLD_SIZE > 1.  Returns (rank, world,
+    local_rank).  backend defaults to nccl (RCCL) when a GPU is present."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def global_mean_loss(local_sum, local_batch):
+    """reduce_mean over the global batch.  local_sum: tensor [1] (or 0-dim)
+    holding this rank's sum of per-image losses.  Returns a 0-dim float32
+    tensor on local_sum's device, identical on every rank."""
+    s = local_sum.reshape(()).to(torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        buf = torch.stack([s, torch.tensor(float(local_batch), dtype=torch.float64, device=s.device)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return (buf[0] / buf[1]).to(torch.float32)
+    return (s / float(local_batch)).to(torch.float32)

@@ -1,0 +1,198 @@
+"""YOLOv3 class API of the reference (YOLOv3.py:11-485) over the HIP
+detection-head path.
+
+Kept from the reference: constructor signature and config / data_provider keys,
+train_one_epoch(lr), test_one_image(images), save_weight / load_weight /
+load_pretraining_weight, _get_priors and _get_normlized_gn.  The backbone and
+head convolutions are outside this path, so the head tensors come from a
+pluggable provider:
+
+  * config['head_provider'] (optional): callable(images) -> [pred1, pred2,
+    pred3], NHWC float32 CUDA tensors [B, H, W, num_priors*(num_classes+5)]
+    (or NCHW when data_format == 'channels_first', transposed here exactly as
+    YOLOv3.py:88-91 does).  Without a provider `images` must already be that
+    list of head tensors.
+  * data_provider['train_generator'] = (initializer, iterator): `initializer`
+    is a callable (or None) run at the start of an epoch, `iterator` yields
+    (images_or_heads, ground_truth[B, pad, 5]) batches; they stand where the
+    reference has a tf.data initializer op and iterator.
+
+train_one_epoch evaluates the loss only; the optimiser step belongs to the
+convolution stack and is not part of this path.
+"""
+import datetime
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .head import DetectionHead
+from . import parallel
+
+
+class YOLOv3:
+    def __init__(self, config, data_provider):
+        assert len(config['data_shape']) == 3
+        assert config['mode'] in ['train', 'test']
+        assert config['data_format'] in ['channels_first', 'channels_last']
+        self.config = config
+        self.data_provider = data_provider
+        self.data_shape = config['data_shape']
+        self.num_classes = config['num_classes']
+        self.weight_decay = config['weight_decay']
+        self.prob = 1. - config['keep_prob']
+        self.data_format = config['data_format']
+        self.mode = config['mode']
+        self.batch_size = config['batch_size'] if config['mode'] == 'train' else 1
+
+        self.coord_sacle = config['coord_scale']
+        self.noobj_scale = config['noobj_scale']
+        self.obj_scale = config['obj_scale']
+        self.class_scale = config['class_scale']
+        self.num_priors = config['num_priors']
+
+        self.nms_score_threshold = config['nms_score_threshold']
+        self.nms_max_boxes = config['nms_max_boxes']
+        self.nms_iou_threshold = config['nms_iou_threshold']
+
+        # YOLOv3.py:37-41: list entry i is divided by stride[i] = 8, 16, 32 and
+        # entry 0 is the one used with the first (coarsest) head (YOLOv3.py:111-113)
+        priors = config['priors']
+        self.stride = [8., 16., 32.]
+        self.priors = [(np.asarray(priors[i], dtype=np.float32) / np.float32(self.stride[i])).reshape(1, 1, -1, 2)
+                       for i in range(len(priors))]
+        self.final_units = (self.num_classes + 5) * self.num_priors
+        self.head_provider = config.get('head_provider')
+
+        if self.mode == 'train':
+            self.num_train = data_provider['num_train']
+            self.train_generator = data_provider['train_generator']
+            self.train_initializer, self.train_iterator = self.train_generator
+            if data_provider['val_generator'] is not None:
+                self.num_val = data_provider['num_val']
+                self.val_generator = data_provider['val_generator']
+                self.val_initializer, self.val_iterator = self.val_generator
+
+        self.global_step = 0
+        self.is_training = True
+        # decode multipliers stride[-1], stride[-1], stride[-2] (YOLOv3.py:346-348);
+        # loss rates stride[-1], stride[-2], stride[-3] (YOLOv3.py:118-120)
+        self.head = DetectionHead(
+            self.num_classes, [p.reshape(-1, 2) for p in self.priors],
+            box_mult=[self.stride[-1], self.stride[-1], self.stride[-2]],
+            gt_rate=[self.stride[-1], self.stride[-2], self.stride[-3]])
+        self.detection_pred = None
+        self.loss = None
+        if self.mode == 'train' and self.train_initializer is not None:
+            self.train_initializer()
+
+    # ------------------------------------------------------------ helpers
+    def _get_priors(self, pshape, priors):
+        """YOLOv3.py:419-433.  pshape = (B, H, W, ...); priors [1,1,P,2] in grid
+        units.  Returns abbox_yx, abbox_hw, abbox_y1x1, abbox_y2x2 as float32
+        arrays [H, W, P, 2]."""
+        H, W = int(pshape[1]), int(pshape[2])
+        priors = np.asarray(priors, dtype=np.float32).reshape(1, 1, -1, 2)
+        P = priors.shape[2]
+        tl = np.stack(np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32),
+                                  indexing='ij'), axis=-1).reshape(H, W, 1, 2)
+        abbox_yx = np.broadcast_to(tl + np.float32(0.5), (H, W, P, 2)).astype(np.float32)
+        abbox_hw = np.broadcast_to(priors, (H, W, P, 2)).astype(np.float32)
+        abbox_y1x1 = abbox_yx - abbox_hw / np.float32(2)
+        abbox_y2x2 = abbox_yx + abbox_hw / np.float32(2)
+        return abbox_yx, abbox_hw, abbox_y1x1, abbox_y2x2
+
+    def _get_normlized_gn(self, downsampling_rate, i):
+        """YOLOv3.py:435-442 on the last ground-truth batch seen."""
+        gt = np.asarray(self.ground_truth[i].detach().cpu().numpy()
+                        if isinstance(self.ground_truth, torch.Tensor) else self.ground_truth[i], dtype=np.float32)
+        slice_index = int(np.argmin(gt[:, 0]))
+        gn = gt[:slice_index] / np.array([downsampling_rate] * 4 + [1], dtype=np.float32).reshape(1, 5)
+        return gn[..., :2], gn[..., 2:4], gn[..., 4].astype(np.int32)
+
+    def _heads_from(self, images):
+        preds = self.head_provider(images) if self.head_provider is not None else images
+        if not isinstance(preds, (list, tuple)) or len(preds) != 3:
+            raise ValueError('three head tensors (pred1, pred2, pred3) are required')
+        preds = list(preds)
+        if self.data_format != 'channels_last':
+            preds = [p.permute(0, 2, 3, 1).contiguous() for p in preds]      # YOLOv3.py:88-91
+        return preds
+
+    # -------------------------------------------------- the path itself
+    def detect_from_heads(self, heads, max_candidates=None):
+        """detection_pred of YOLOv3.py:319-368 for every image of the batch;
+        returns head.Detections (device resident)."""
+        return self.head.detect(heads, self.nms_score_threshold, self.nms_iou_threshold,
+                                self.nms_max_boxes, max_candidates)
+
+    def loss_from_heads(self, heads, ground_truth, want_parts=False):
+        """total_loss of YOLOv3.py:116-311 (reduce_mean of the per-image
+        losses) as a 0-dim CUDA tensor; with torch.distributed initialised the
+        mean is taken over the global batch (one scalar all-reduce)."""
+        out = self.head.loss(heads, ground_truth, self.coord_sacle, self.noobj_scale, self.obj_scale,
+                             self.class_scale, ignore_threshold=0.5, normalize_by_num_gt=True,
+                             want_parts=want_parts)
+        total = parallel.global_mean_loss(out['sum'], heads[0].shape[0])
+        return (total, out) if want_parts else total
+
+    def _weight_l2(self):
+        fn = getattr(self.head_provider, 'l2_loss_sum', None)
+        return float(fn()) if fn is not None else 0.0
+
+    # ------------------------------------------------------- public API
+    def train_one_epoch(self, lr):
+        self.is_training = True
+        if self.train_initializer is not None:
+            self.train_initializer()
+        mean_loss = []
+        num_iters = self.num_train // self.batch_size
+        for i in range(num_iters):
+            images, ground_truth = next(self.train_iterator)
+            self.ground_truth = ground_truth
+            heads = self._heads_from(images)
+            total_loss = self.loss_from_heads(heads, ground_truth)
+            # YOLOv3.py:313-315: .5 * total_loss + weight_decay * sum(l2_loss(var))
+            loss = np.float32(.5 * float(total_loss.item()) + self.weight_decay * self._weight_l2())
+            self.loss = loss
+            self.global_step += 1
+            sys.stdout.write('\r>> ' + 'iters '+str(i)+str('/')+str(num_iters)+' loss '+str(loss))
+            sys.stdout.flush()
+            mean_loss.append(loss)
+        sys.stdout.write('\n')
+        mean_loss = np.mean(mean_loss)
+        return mean_loss
+
+    def test_one_image(self, images):
+        self.is_training = False
+        print(datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S.%f'))
+        heads = self._heads_from(images)
+        heads = [h[:1] for h in heads]                       # YOLOv3.py:320-331: image 0 only
+        scores, bbox, class_id, _ = self.detect_from_heads(heads).per_image()[0]
+        pred = [scores, bbox, class_id]
+        self.detection_pred = pred
+        print(datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S.%f'))
+        return pred
+
+    def save_weight(self, mode, path):
+        assert(mode in ['latest', 'best'])
+        if os.path.dirname(path) and not os.path.exists(os.path.dirname(path)):
+            os.makedirs(os.path.dirname(path))
+            print(os.path.dirname(path), 'does not exist, create it done')
+        fn = getattr(self.head_provider, 'save', None)
+        if fn is not None:
+            fn('%s-%d' % (path, self.global_step))
+        print('save', mode, 'model in', path, 'successfully')
+
+    def load_weight(self, path):
+        fn = getattr(self.head_provider, 'load', None)
+        if fn is not None:
+            fn(path)
+        print('load weight', path, 'successfully')
+
+    def load_pretraining_weight(self, path):
+        fn = getattr(self.head_provider, 'load_pretraining', None)
+        if fn is not None:
+            fn(path)
+        print('load pretraining weight', path, 'successfully')

@@ -1,0 +1,33 @@
+"""Worker of test_two_rank_gloo_loss_mean_matches_full_batch (not collected)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import yolo_tf_amd as y                                    # noqa: E402
+from oracle import c_oracle as co                          # noqa: E402
+from tests import cases                                    # noqa: E402
+
+rank, world, _ = y.parallel.init_from_env(backend='gloo')
+assert world == 2 and dist.get_backend() == 'gloo'
+case = cases.v3(size=160, C=6)
+B = 7                                                       # uneven split: 4 + 3
+heads = case.heads(5, B)
+gt = case.gt(6, B, 8, 12)
+cfg = case.oracle_cfg(co)
+per_full, _, _, mean_full = co.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.5, True)
+b0, b1 = y.parallel.shard_range(B, rank, world)
+per_local, _, _, _ = co.loss(cfg, [h[b0:b1] for h in heads], gt[b0:b1], (1., 1., 5., 1.), 0.5, True)
+assert np.array_equal(per_local, per_full[b0:b1])          # images are independent
+local_sum = torch.tensor([float(np.sum(per_local.astype(np.float64)))], dtype=torch.float32)
+mean = y.parallel.global_mean_loss(local_sum, b1 - b0)
+np.testing.assert_allclose(float(mean), float(mean_full), rtol=1e-6)
+gathered = [torch.zeros(()) for _ in range(world)]
+dist.all_gather(gathered, mean)
+assert float(gathered[0]) == float(gathered[1])             # identical on every rank
+print('GLOO_OK rank %d mean %.6f' % (rank, float(mean)))
+dist.destroy_process_group()

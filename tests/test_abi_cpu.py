@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares,
+validates arguments on the host and refuses to compute without a HIP device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import yolo_tf_amd as y
+from yolo_tf_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'yolohead.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(yh_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _abi.load()
+    names = header_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), 'libyolohead.so does not export %s' % n
+        assert n in _abi.SIGNATURES, '_abi.py does not bind %s' % n
+    assert sorted(_abi.SIGNATURES) == names
+    assert lib.yh_version() >= 100
+
+
+def test_config_struct_layout_matches_header():
+    assert ctypes.sizeof(_abi.HeadConfig) == 4 * 3 + 4 * 4 * 4 + 4 * 16 * 2 * 4
+    cfg = y.make_config([(13, 13), (26, 26)], [[[1, 2], [3, 4]], [[5, 6], [7, 8]]], [32, 16], [32, 16], 7)
+    assert (cfg.num_scales, cfg.num_priors, cfg.num_classes) == (2, 2, 7)
+    assert cfg.prior_hw[1][1][0] == 7.0 and cfg.grid_w[1] == 26 and cfg.box_mult[1] == 16.0
+    n = ctypes.c_int64(0)
+    _abi.check(_abi.load().yh_boxes_per_image(ctypes.byref(cfg), ctypes.byref(n)))
+    assert n.value == (13 * 13 + 26 * 26) * 2
+
+
+def test_host_side_validation_needs_no_gpu():
+    lib = _abi.load()
+    cfg = y.make_config([(13, 13)], [y.synth.V2_PRIORS], [32], [32], 20)
+    nbytes = ctypes.c_size_t(0)
+    _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), 4, 1000, 10, ctypes.byref(nbytes)))
+    assert nbytes.value >= 2 * 4 * 1000 * 8 + 4 * 845 * 16
+    _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), 4, 60, ctypes.byref(nbytes)))
+    assert nbytes.value > 0
+    bad = y.make_config([(13, 13)], [y.synth.V2_PRIORS], [32], [32], 20)
+    bad.num_classes = 5000
+    assert lib.yh_detect_workspace_bytes(ctypes.byref(bad), 4, 1000, 10, ctypes.byref(nbytes)) == _abi.YH_ERR_LIMIT
+    assert b'num_classes' in lib.yh_last_error()
+    big = y.make_config([(1024, 1024)], [y.synth.V2_PRIORS], [32], [32], 20)
+    assert lib.yh_boxes_per_image(ctypes.byref(big), ctypes.byref(ctypes.c_int64(0))) == _abi.YH_ERR_LIMIT
+    assert lib.yh_detect_workspace_bytes(ctypes.byref(cfg), 4, 1000, 100000, ctypes.byref(nbytes)) == _abi.YH_ERR_INVALID_ARG
+    with pytest.raises(_abi.YhError):
+        _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), 4, 0, ctypes.byref(nbytes)))
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a HIP device is present')
+    n = ctypes.c_int32(7)
+    assert _abi.load().yh_device_count(ctypes.byref(n)) == _abi.YH_ERR_NO_DEVICE and n.value == 0
+    hd = y.DetectionHead(20, [y.synth.V2_PRIORS], [32.0], [32.0])
+    heads = [torch.zeros((1, 13, 13, 125))]
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hd.detect(heads, 0.5, 0.5, 10)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hd.decode(heads)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hd.loss(heads, torch.zeros((1, 4, 5)), 1, 1, 5, 1, 0.6, False)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'yolo-tf_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')) or f == 'Makefile':
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.lower(), '%s mentions the oracle' % os.path.join(dirpath, f)

@@ -1,0 +1,159 @@
+"""CPU: the two restatements of the reference (NumPy, C) against each other and
+against the committed golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import yolo_tf_amd as y
+from oracle import yolo_head_oracle as O
+from tests import cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+
+
+def golden_heads(g):
+    return [g['head%d' % s] for s in range(g['grids'].shape[0])]
+
+
+@pytest.mark.parametrize('name', ['detect_v2_416_voc', 'detect_v3_160'])
+def test_detect_golden(c_oracle, name):
+    g = load(name)
+    heads = golden_heads(g)
+    C = int(g['num_classes']); thr = float(g['score_threshold']); iou = float(g['iou_threshold']); mb = int(g['max_boxes'])
+    priors = list(g['priors'])
+    # NumPy restatement reproduces the fixture exactly
+    off = 0
+    for b in range(heads[0].shape[0]):
+        bb, cf = O.decode([h[b] for h in heads], priors, g['box_mult'], C)
+        assert np.array_equal(bb, g['bbox'][b]) and np.array_equal(cf, g['conf'][b])
+        s, bx, cl, ix = O.nms_per_class(bb, cf, thr, mb, iou)
+        k = int(g['det_count'][b])
+        assert np.array_equal(ix, g['det_index'][off:off + k]) and np.array_equal(cl, g['det_class'][off:off + k])
+        assert np.array_equal(s, g['det_scores'][off:off + k])
+        off += k
+    # C restatement: same kept rows, values within 1e-5
+    cfg = c_oracle.make_config([tuple(x) for x in g['grids']], priors, g['box_mult'], [1.0] * len(priors), C)
+    got = c_oracle.detect(cfg, heads, thr, iou, mb)
+    off = 0
+    for b, (s, bx, cl, ix) in enumerate(got):
+        k = int(g['det_count'][b])
+        assert np.array_equal(ix, g['det_index'][off:off + k]) and np.array_equal(cl, g['det_class'][off:off + k])
+        np.testing.assert_allclose(s, g['det_scores'][off:off + k], rtol=1e-5)
+        np.testing.assert_allclose(bx, g['det_bbox'][off:off + k], rtol=1e-5, atol=1e-3)
+        off += k
+
+
+@pytest.mark.parametrize('name', ['loss_v3_160', 'loss_v2_416_voc'])
+def test_loss_golden(c_oracle, name):
+    g = load(name)
+    heads = golden_heads(g)
+    C = int(g['num_classes']); priors = list(g['priors']); v = int(g['version'])
+    if v == 3:
+        per, mean = O.loss_v3_batch(heads, g['ground_truth'], priors, C)
+    else:
+        per, mean = O.loss_v2_batch(heads[0], g['ground_truth'], priors[0], C)
+    assert np.array_equal(per, g['loss_per_image']) and mean == g['loss_mean']
+    cfg = c_oracle.make_config([tuple(x) for x in g['grids']], priors, [1.0] * len(priors), g['gt_rate'], C)
+    cper, cparts, ciou, cmean = c_oracle.loss(cfg, heads, g['ground_truth'], g['loss_scales'],
+                                              float(g['ignore_threshold']), v == 3, want_iou=True)
+    np.testing.assert_allclose(cper, g['loss_per_image'], rtol=1e-5)
+    np.testing.assert_allclose(cparts, g['loss_parts'], rtol=1e-5)
+    np.testing.assert_allclose(cmean, g['loss_mean'], rtol=1e-5)
+    # IoU is + - * / min max only: both restatements give the same bits
+    assert np.array_equal(ciou.view(np.uint32), g['iou_max'].view(np.uint32))
+
+
+def test_restatements_agree_on_v3_416(c_oracle):
+    case = cases.v3()
+    heads = case.heads(7, 2)
+    cfg = case.oracle_cfg(c_oracle)
+    cb, cc = c_oracle.decode(cfg, heads)
+    for b in range(2):
+        nb, nc = O.decode([h[b] for h in heads], case.priors, case.box_mult, case.C)
+        np.testing.assert_allclose(cb[b], nb, rtol=1e-5, atol=1e-5 * 416)
+        np.testing.assert_allclose(cc[b], nc, rtol=1e-5, atol=1e-30)
+    got = c_oracle.detect(cfg, heads, 0.5, 0.5, 10)
+    for b in range(2):
+        s, bx, cl, ix = O.detect([h[b] for h in heads], case.priors, case.box_mult, case.C, 0.5, 10, 0.5)
+        assert np.array_equal(ix, got[b][3]) and np.array_equal(cl, got[b][2]) and len(ix) > 0
+    gt = case.gt(8, 2, 100, 101)
+    per, parts, iou, mean = c_oracle.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.5, True, want_iou=True)
+    nper, nmean = O.loss_v3_batch(heads, gt, case.priors, case.C)
+    np.testing.assert_allclose(per, nper, rtol=1e-5)
+    np.testing.assert_allclose(mean, nmean, rtol=1e-5)
+    ni = O.noobj_iou_max([h[0] for h in heads], gt[0], case.priors, case.gt_rate, case.C)
+    assert np.array_equal(ni.view(np.uint32), iou[0].view(np.uint32))
+
+
+def test_restatements_agree_on_v2_and_c_threads(c_oracle):
+    case = cases.v2(size=480)
+    heads = case.heads(9, 4)
+    gt = case.gt(10, 4, 9, 60)
+    cfg = case.oracle_cfg(c_oracle)
+    per, _, _, mean = c_oracle.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.6, False)
+    per4, _, _, _ = c_oracle.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.6, False, threads=4)
+    assert np.array_equal(per, per4)
+    nper, nmean = O.loss_v2_batch(heads[0], gt, case.priors[0], case.C)
+    np.testing.assert_allclose(per, nper, rtol=1e-5)
+    a = c_oracle.detect(cfg, heads, 0.4, 0.5, 10)
+    b = c_oracle.detect(cfg, heads, 0.4, 0.5, 10, threads=4)
+    cases.same_detections(a, b)
+
+
+def test_nms_semantics():
+    """Hand-made boxes: strict '>' on the IoU threshold, suppression only by
+    SELECTED boxes, max_output_size, corner normalisation, zero-area boxes,
+    lower index first among equal scores."""
+    b = np.array([[0, 0, 10, 10],      # 0: best
+                  [0, 0, 10, 5],       # 1: IoU with 0 = 0.5 exactly -> not suppressed at thr 0.5
+                  [0, 1, 10, 10],      # 2: IoU with 0 = 0.9 -> suppressed
+                  [10, 0.5, 0, 0],     # 3: flipped corners; IoU with 0 = 0.05; with 1 = 0.1
+                  [20, 20, 20, 30],    # 4: zero area: never suppressed
+                  [0, 1, 10, 10]], np.float32)   # 5: same as 2 -> suppressed by 0
+    s = np.array([0.9, 0.8, 0.7, 0.6, 0.5, 0.7], np.float32)
+    sel = O.non_max_suppression(b, s, 10, 0.5)
+    assert sel.tolist() == [0, 1, 3, 4]
+    assert O.non_max_suppression(b, s, 2, 0.5).tolist() == [0, 1]
+    # 2 and 5 tie: with 0 removed they are taken in index order, 5 suppressed by 2
+    assert O.non_max_suppression(b[1:], s[1:], 10, 0.5).tolist() == [0, 1, 2, 3]
+    # a suppressed box does not suppress: chain a-b-c with IoU(a,b), IoU(b,c) high, IoU(a,c) low
+    c = np.array([[0, 0, 10, 10], [0, 4, 10, 14], [0, 8, 10, 18]], np.float32)
+    assert O.non_max_suppression(c, np.array([.9, .8, .7], np.float32), 10, 0.3).tolist() == [0, 2]
+    with pytest.raises(ValueError):
+        O.non_max_suppression(b, s, 10, 1.5)
+
+
+def test_loss_formula_pieces():
+    x = np.array([-3., 0., 2.5], np.float32); z = np.array([0., 1., 0.3], np.float32)
+    want = -(z * np.log(O.sigmoid(x).astype(np.float64)) + (1 - z) * np.log(1 - O.sigmoid(x).astype(np.float64)))
+    np.testing.assert_allclose(O.sigmoid_ce(x, z), want, rtol=1e-5)
+    import torch
+    t = torch.nn.functional.binary_cross_entropy_with_logits(torch.from_numpy(x), torch.from_numpy(z), reduction='none')
+    np.testing.assert_allclose(O.sigmoid_ce(x, z), t.numpy(), rtol=1e-6)
+    assert O.one_hot(np.array([1, 7, -1]), 3).tolist() == [[0, 1, 0], [0, 0, 0], [0, 0, 0]]
+    gt = np.array([[5, 6, 7, 8, 2], [9, 9, 9, 9, 1], [-1, -1, -1, -1, -1], [-1, -1, -1, -1, -1]], np.float32)
+    yx, hw, lab = O.normalized_gn(gt, 2.0)
+    assert yx.shape == (2, 2) and lab.tolist() == [2, 1] and hw[0].tolist() == [3.5, 4.0]
+    # priors: centre + 0.5, (y, x) order
+    a_yx, a_hw, a1, a2 = O.get_priors(2, 3, [[1., 2.]])
+    assert a_yx[1, 2, 0].tolist() == [1.5, 2.5] and a1[0, 0, 0].tolist() == [0.0, -0.5]
+
+
+def test_v3_quirks():
+    """Scale pairing and multipliers the reference really uses."""
+    p = O.v3_grid_priors(y.synth.V3_PRIORS)
+    np.testing.assert_allclose(p[0][0], [10 / 8., 13 / 8.])          # coarse grid <- small priors / 8
+    np.testing.assert_allclose(p[2][2], [373 / 32., 326 / 32.])
+    assert O.V3_BOX_MULT == (32.0, 32.0, 16.0) and O.V3_GT_RATE == (32.0, 16.0, 8.0)
+    # additive hw decode: zero logits give hw = prior + 1
+    h = [np.zeros((1, 1, 3 * 7), np.float32)] * 3
+    bb, cf = O.decode(h, p, O.V3_BOX_MULT, 2)
+    np.testing.assert_allclose(bb[0], [(1.0 - (10 / 8. + 1) / 2) * 32, (1.0 - (13 / 8. + 1) / 2) * 32,
+                                       (1.0 + (10 / 8. + 1) / 2) * 32, (1.0 + (13 / 8. + 1) / 2) * 32], rtol=1e-6)
+    assert np.all(cf == np.float32(0.25))

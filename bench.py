@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the detection-head hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A step is one pass of the path over one batch of synthetic head tensors that
+are resident in HBM before the timed region starts.  For N > 1 the driver
+launches one rank per GPU (torch.distributed.run); images are sharded by rank
+(weak scaling: every rank owns a full per-GPU batch), the detect workloads need
+no collective and the loss workload all-reduces one scalar over RCCL.
+
+Workloads (BASELINE.json configs):
+  detect416  config 2  YOLOv3-416 COCO-80, batch 64 / GPU, decode + score filter + per-class NMS   [default]
+  loss416    config 3  YOLOv3-416 loss, 100 GT / image, batch 32 / GPU
+  detect608  config 4  YOLOv3-608 COCO-80, batch 64 / GPU
+  stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 16 / GPU
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the
+streaming pass over the head tensor) with HIP events recorded around it on the
+launch stream inside the timed region; `cpu_baseline` times the C restatement
+of the reference's arithmetic (oracle/, "port") on this host's cores for a
+bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import yolo_tf_amd as y                                    # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+ROTATE = 4                       # distinct input sets, so that no step re-reads data the 256 MiB Infinity Cache still holds
+
+WORKLOADS = {
+    'detect416': dict(kind='detect', size=416, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
+                      name='YOLOv3 416x416 COCO-80 decode+NMS, synthetic head tensors, 10647 boxes/img'),
+    'detect608': dict(kind='detect', size=608, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
+                      name='YOLOv3 608x608 COCO-80 decode+NMS, synthetic head tensors, 22743 boxes/img'),
+    'stress': dict(kind='detect', size=None, C=80, batch=16, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
+                   name='NMS stress: 100x100 grid x 10 priors, ~1e5 candidates/img at score_thresh 0.001, 80 classes'),
+    'loss416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101,
+                    name='YOLOv3 416x416 training loss path: 100 GT boxes/img IoU ignore-mask + target assignment'),
+}
+
+
+def build_head(w):
+    if w['size'] is None:
+        rng = np.random.Generator(np.random.PCG64(99))
+        priors = [rng.uniform(0.5, 4.0, size=(10, 2)).astype(np.float32)]
+        grids = [(100, 100)]
+        return grids, priors, (32.0,), (32.0,)
+    s = [8., 16., 32.]
+    priors = [(np.asarray(y.synth.V3_PRIORS[i], np.float32) / np.float32(s[i])) for i in range(3)]
+    return y.synth.v3_grids(w['size']), priors, (32.0, 32.0, 16.0), (32.0, 16.0, 8.0)
+
+
+def cpu_baseline(w, grids, priors, box_mult, gt_rate, budget_s=12.0):
+    """Times the C restatement on the host cores for a bounded sample."""
+    from oracle import c_oracle as co
+    threads = max(1, min(16, int(os.environ.get('OMP_NUM_THREADS', '0')) or (os.cpu_count() or 1)))
+    cfg = co.make_config(grids, priors, box_mult, gt_rate, w['C'])
+    P = len(priors[0])
+    Bs = 2 * threads
+    heads = y.synth.make_heads(4242, Bs, grids, P, w['C'], **w.get('dist', {}))
+    if w['kind'] == 'detect':
+        fn = lambda: co.detect(cfg, heads, w['thr'], w['iou'], w['max_boxes'], threads=threads, unpack=False)
+    else:
+        gt = y.synth.make_ground_truth(4243, Bs, w['G'], w['pad'], w['size'], w['C'])
+        fn = lambda: co.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.5, True, threads=threads)
+    fn()                                                    # warm-up (page-in, thread pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn(); reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 10000:
+            break
+    return dict(value=round(Bs * reps / el, 2), unit='images/sec', cores=threads, kind='port',
+                sample='%d synthetic images x %d passes (%.1f s) of the same workload, C restatement of the '
+                       'reference op sequence (oracle/yolo_head_oracle.c), OpenMP over images' % (Bs, reps, el))
+
+
+def load_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile, if one exists."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='detect416', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local_rank = y.parallel.init_from_env()
+    if world != max(1, args.gpus):
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the path has no CPU fallback')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    w = dict(WORKLOADS[args.workload])
+    B = args.batch or w['batch']
+    grids, priors, box_mult, gt_rate = build_head(w)
+    P, C = len(priors[0]), w['C']
+    hd = y.DetectionHead(C, priors, box_mult, gt_rate)
+    N = sum(h * ww * P for h, ww in grids)
+    bytes_img = N * (C + 5) * 4
+
+    sets = [y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(ROTATE)]
+    steps, warmup = args.steps, args.warmup
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:                                         # force creation of the hipEvent_t handles
+        a.record(); b.record()
+
+    if w['kind'] == 'detect':
+        outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
+
+        def step(i, events=None):
+            return hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs,
+                             stream_events=events)
+        extra = {}
+    else:
+        gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
+               for i in range(ROTATE)]
+
+        def step(i, events=None):
+            out = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
+            return y.parallel.global_mean_loss(out['sum'], B)   # the data-parallel scalar all-reduce
+        extra = {}
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    last = None
+    for i in range(warmup):
+        last = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if w['kind'] == 'detect':
+            last = step(i, (ev[i][0].cuda_event, ev[i][1].cuda_event))
+        else:
+            last = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if w['kind'] == 'detect':
+        if last.overflowed():
+            raise SystemExit('candidate capacity overflow in the benchmark configuration')
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        extra['detections_per_image_last_step'] = round(float(last.count.float().mean().item()), 2)
+    else:
+        kern_ms = None
+        extra['mean_loss_last_step'] = float(last.item())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * B * steps / elapsed
+        res = {
+            'metric': 'images/sec (decode+IoU+NMS) YOLOv3-416 COCO-80 at 1/2/4/8 GPU; % HBM peak',
+            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(1e3 * elapsed / steps, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=B * world,
+                           boxes_per_image=N, num_classes=C, bytes_per_image=bytes_img,
+                           parallelism='images sharded across %d GPU(s), no data-path collective' % world
+                           if w['kind'] == 'detect' else
+                           'images sharded across %d GPU(s), one scalar all-reduce (RCCL) per step' % world,
+                           input_rotation='%d distinct input sets (%.0f MB each) so the 256 MiB Infinity Cache cannot serve a step'
+                                          % (ROTATE, B * bytes_img / 1e6), **extra),
+        }
+        if kern_ms is not None:
+            ach = B * bytes_img / (kern_ms * 1e-3) / 1e9
+            res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                   frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
+                                   kernel='k_stream<detect> (decode + score filter + compaction)',
+                                   kernel_ms=round(kern_ms, 5), algorithmic_bytes_per_launch=B * bytes_img,
+                                   whole_pipeline_frac=round(value / world * bytes_img / 1e9 / HBM_PEAK_GBS, 4))
+        else:
+            ach = value / world * bytes_img / 1e9
+            res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                   frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
+                                   kernel='whole loss step (k_loss_pos + k_loss_neg + k_loss_finalize), wall clock',
+                                   algorithmic_bytes_per_launch=B * bytes_img)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(w, grids, priors, box_mult, gt_rate)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

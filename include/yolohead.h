@@ -111,6 +111,17 @@ int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batc
               int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
               int32_t *status, void *stream);
 
+/* yh_detect with two caller-created hipEvent_t (as void*, either may be NULL)
+ * recorded on `stream` immediately before and after the streaming kernel
+ * (decode + score filter + compaction), so that a benchmark can time the
+ * dominant kernel alone.  Measurement hook: no counterpart in the reference. */
+int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                    float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                    int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                    int32_t *out_count, float *out_scores, float *out_boxes,
+                    int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                    int32_t *status, void *stream, void *event_begin, void *event_end);
+
 /* The same pipeline entered after the decode: replaces YOLOv3.py:351-368 /
  * YOLOv2.py:193-210 on caller-supplied boxes [B][N][4] and conf [B][N][C].
  * Workspace: yh_nms_workspace_bytes. */

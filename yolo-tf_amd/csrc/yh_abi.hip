@@ -282,12 +282,12 @@ static int run_nms_stage(const DetectWs &w, int32_t B, int32_t C, int32_t N, con
     return YH_OK;
 }
 
-int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+static int detect_impl(const yh_head_config *cfg, const float *const *heads, int32_t batch,
               float score_threshold, float iou_threshold, int32_t nms_max_boxes,
               int32_t max_candidates, void *workspace, size_t workspace_bytes,
               int32_t *out_count, float *out_scores, float *out_boxes,
               int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
-              int32_t *status, void *stream)
+              int32_t *status, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     int rc = check_config(cfg);
     if (rc != YH_OK) return rc;
@@ -305,10 +305,8 @@ int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batc
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e = hipMemsetAsync(w.img_count, 0, (size_t)batch * 4, st);
-    if (e != hipSuccess) return hip_fail(e, "memset counters");
-    e = hipMemsetAsync(status, 0, 4, st);
-    if (e != hipSuccess) return hip_fail(e, "memset status");
+    hipError_t e = yh::launch_reset(w.img_count, batch, status, st);
+    if (e != hipSuccess) return hip_fail(e, "reset launch");
 
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, heads, batch);
@@ -319,11 +317,38 @@ int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batc
     p.img_count = w.img_count;
     p.boxes = w.boxes;
     const uint32_t blocks = plan_stream(p, batch);
+    if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return hip_fail(e, "event record");
     e = yh::launch_stream(p, yh::kModeDetect, blocks, st);
     if (e != hipSuccess) return hip_fail(e, "detect stream launch");
+    if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return hip_fail(e, "event record");
     return run_nms_stage(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold, nms_max_boxes,
                          max_candidates, out_count, out_scores, out_boxes, out_class, out_index,
                          out_class_candidates, status, st);
+}
+
+int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+              int32_t max_candidates, void *workspace, size_t workspace_bytes,
+              int32_t *out_count, float *out_scores, float *out_boxes,
+              int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+              int32_t *status, void *stream)
+{
+    return detect_impl(cfg, heads, batch, score_threshold, iou_threshold, nms_max_boxes, max_candidates,
+                       workspace, workspace_bytes, out_count, out_scores, out_boxes, out_class, out_index,
+                       out_class_candidates, status, stream, nullptr, nullptr);
+}
+
+int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                    float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                    int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                    int32_t *out_count, float *out_scores, float *out_boxes,
+                    int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                    int32_t *status, void *stream, void *event_begin, void *event_end)
+{
+    return detect_impl(cfg, heads, batch, score_threshold, iou_threshold, nms_max_boxes, max_candidates,
+                       workspace, workspace_bytes, out_count, out_scores, out_boxes, out_class, out_index,
+                       out_class_candidates, status, stream, static_cast<hipEvent_t>(event_begin),
+                       static_cast<hipEvent_t>(event_end));
 }
 
 int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
@@ -354,10 +379,8 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e = hipMemsetAsync(w.img_count, 0, (size_t)batch * 4, st);
-    if (e != hipSuccess) return hip_fail(e, "memset counters");
-    e = hipMemsetAsync(status, 0, 4, st);
-    if (e != hipSuccess) return hip_fail(e, "memset status");
+    hipError_t e = yh::launch_reset(w.img_count, batch, status, st);
+    if (e != hipSuccess) return hip_fail(e, "reset launch");
 
     // the confidence matrix is streamed as a one-scale "head" whose rows hold C channels
     yh::StreamParams p;

@@ -101,6 +101,8 @@ struct NmsParams {
 };
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
+// zeroes the per-image candidate counters and the status word (one launch)
+hipError_t launch_reset(int32_t *img_count, int32_t batch, int32_t *status, hipStream_t st);
 
 // ---- loss ------------------------------------------------------------------
 struct LossScale {

@@ -270,6 +270,19 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p)
     if (tid == 0) p.out_count[b] = s_off[C - 1] + p.kept_cnt[b * C + C - 1];
 }
 
+__global__ __launch_bounds__(256) void k_reset(int32_t *img_count, int32_t batch, int32_t *status)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < batch) img_count[i] = 0;
+    if (i == 0) *status = 0;
+}
+
+hipError_t launch_reset(int32_t *img_count, int32_t batch, int32_t *status, hipStream_t stm)
+{
+    hipLaunchKernelGGL(k_reset, dim3((batch + 255) / 256), dim3(256), 0, stm, img_count, batch, status);
+    return hipGetLastError();
+}
+
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;

@@ -92,6 +92,7 @@ class DetectionHead:
         self.box_mult = [float(m) for m in box_mult]
         self.gt_rate = [float(r) for r in gt_rate]
         self._ws = {}
+        self._plans = {}
 
     # ------------------------------------------------------------ helpers
     def _check_heads(self, heads):
@@ -162,29 +163,41 @@ class DetectionHead:
         return count, scores, boxes, cls, idx, cc, status
 
     def detect(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-               want_class_candidates=False, outputs=None):
+               want_class_candidates=False, outputs=None, stream_events=None):
         """Decode + score filter + per-class NMS for every image (YOLOv3.py:320-368).
         Enqueues on the current stream and returns device tensors; nothing
-        synchronises until the result is read."""
+        synchronises until the result is read.  outputs: a tuple from
+        _alloc_outputs to write into (reused across calls by the caller)."""
         lib = _abi.load()
         heads = self._check_heads(heads)
-        cfg = self.config_for(heads)
-        B, N = heads[0].shape[0], self.boxes_per_image(heads)
         dev = heads[0].device
-        cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
-        nbytes = ctypes.c_size_t(0)
-        _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
-        ws = self._workspace(('detect', B, N, cap, int(max_boxes)), nbytes.value, dev)
+        # geometry, capacity and workspace depend only on the shapes: planned once per shape
+        key = ('detect', tuple(tuple(h.shape) for h in heads), max_candidates, int(max_boxes), dev)
+        plan = self._plans.get(key)
+        if plan is None:
+            cfg = self.config_for(heads)
+            B, N = heads[0].shape[0], self.boxes_per_image(heads)
+            cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
+            nbytes = ctypes.c_size_t(0)
+            _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
+            ws = self._workspace(('detect', B, N, cap, int(max_boxes)), nbytes.value, dev)
+            plan = self._plans[key] = (cfg, B, N, cap, ws)
+        cfg, B, N, cap, ws = plan
         if outputs is None:
             outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
         count, scores, boxes, cls, idx, cc, status = outputs
+        args = [ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
+                float(score_threshold), float(iou_threshold), int(max_boxes), cap,
+                ws.data_ptr(), ws.numel(), count.data_ptr(), scores.data_ptr(),
+                boxes.data_ptr(), cls.data_ptr(), idx.data_ptr(),
+                cc.data_ptr() if cc is not None else None, status.data_ptr(), self._stream(dev)]
         with torch.cuda.device(dev):
-            _abi.check(lib.yh_detect(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
-                                     float(score_threshold), float(iou_threshold), int(max_boxes), cap,
-                                     ws.data_ptr(), ws.numel(), count.data_ptr(), scores.data_ptr(),
-                                     boxes.data_ptr(), cls.data_ptr(), idx.data_ptr(),
-                                     cc.data_ptr() if cc is not None else None, status.data_ptr(),
-                                     self._stream(dev)))
+            if stream_events is None:
+                _abi.check(lib.yh_detect(*args))
+            else:
+                # (begin, end): raw hipEvent_t handles recorded around the streaming kernel
+                _abi.check(lib.yh_detect_timed(*args, ctypes.c_void_p(stream_events[0]),
+                                               ctypes.c_void_p(stream_events[1])))
         full = N * self.num_classes
         rerun = None
         if cap < full:

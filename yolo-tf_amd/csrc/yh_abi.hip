@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include "yh_internal.h"
@@ -132,24 +133,34 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
     return YH_OK;
 }
 
-// Fills the per-scale stream descriptors and the block decomposition.
+// Fills the per-scale block decomposition of the streaming pass.  A workgroup
+// walks tiles of whole rows (<= 32 KiB each) and ends with a latency-bound tail
+// (the atomic that reserves its candidate range), so the launch is
+// oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
+constexpr uint64_t kStreamTargetBlocks = 3600;
+
 uint32_t plan_stream(yh::StreamParams &p, int B)
 {
-    // total float4 slots; a workgroup takes a multiple of the slot granule, sized
-    // so that the launch has a few thousand workgroups (>> 256 CUs) while each
-    // flushes its candidates with a single atomic
-    uint64_t total_slots = 0;
-    for (int s = 0; s < p.S; ++s) total_slots += ((uint64_t)p.sc[s].span + 3) / 4 * (uint64_t)B;
-    uint64_t m = total_slots / 4096 / yh::kStreamSlotGranule;
-    if (m < 1) m = 1;
-    if (m > 8) m = 8;
-    p.chunk_slots = (uint32_t)(m * yh::kStreamSlotGranule);
+    p.tile_rows = (yh::kTileFloats - 3) / p.K;
+    uint64_t total_tiles = 0;
+    for (int s = 0; s < p.S; ++s)
+        total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
+    uint64_t want = kStreamTargetBlocks;
+    if (const char *e = std::getenv("YH_STREAM_BLOCKS")) {      // tuning knob
+        const long v = std::atol(e);
+        if (v > 0) want = (uint64_t)v;
+    }
+    uint64_t tpc = (total_tiles + want / 2) / want;              // tiles per workgroup, nearest
+    if (tpc < 1) tpc = 1;
+    if (tpc > 64) tpc = 64;
     uint32_t blocks = 0;
     for (int s = 0; s < p.S; ++s) {
-        const uint64_t slots_img = ((uint64_t)p.sc[s].span + 6) / 4 + 1;   // any 16-byte phase of the image start
-        p.sc[s].chunks_per_img = (uint32_t)((slots_img + p.chunk_slots - 1) / p.chunk_slots);
+        const uint64_t tiles_img = ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows;
+        const uint64_t chunks = (tiles_img + tpc - 1) / tpc;
+        p.sc[s].tiles_per_chunk = (uint32_t)((tiles_img + chunks - 1) / chunks);   // even split
+        p.sc[s].chunks_per_img = (uint32_t)chunks;
         p.sc[s].blk_begin = blocks;
-        blocks += p.sc[s].chunks_per_img * (uint32_t)B;
+        blocks += (uint32_t)chunks * (uint32_t)B;
     }
     return blocks;
 }

@@ -52,6 +52,7 @@ struct StreamScale {
     uint32_t row_base;      // first box row of this scale inside an image
     uint32_t blk_begin;     // first block of this scale
     uint32_t chunks_per_img;
+    uint32_t tiles_per_chunk;   // tiles one workgroup walks
     float mult;
     float prior_hw[YH_MAX_PRIORS][2];
 };
@@ -59,7 +60,7 @@ struct StreamScale {
 struct StreamParams {
     int32_t S, B, C, P, K, N;
     uint32_t magic_k;       // floor(2^32 / K) + 1
-    uint32_t chunk_slots;   // float4 slots per block (multiple of 256 * kUnroll)
+    int32_t tile_rows;      // rows per LDS tile: floor((kTileFloats - 3) / K)
     float thr;              // score threshold
     float prefilter;        // logits below this cannot reach thr
     int32_t cand_cap;
@@ -70,7 +71,7 @@ struct StreamParams {
     StreamScale sc[YH_MAX_SCALES];
 };
 
-constexpr uint32_t kStreamSlotGranule = 256 * 8;   // slots one workgroup reads per loop trip
+constexpr int kTileFloats = 8192;                   // LDS tile of the streaming pass: 32 KiB
 
 enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
 

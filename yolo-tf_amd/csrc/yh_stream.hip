@@ -1,37 +1,43 @@
 // Streaming pass over the head tensor: decode, score filter and candidate
 // compaction in one read of HBM.  Replaces YOLOv3.py:338-357 / YOLOv2.py:183-199.
 //
-// The NHWC head of one scale is a row-major matrix [B * rows_img][K], K = C + 5.
-// A workgroup owns a run of 16-byte slots of one image and every lane reads
-// whole float4 slots of the flat stream (lane i -> base + 16 * i), so the HBM
-// access is fully coalesced whatever K is.  The loads of one loop trip are
-// unconditional (indices are clamped, results masked), so eight of them are in
-// flight per lane before the first is consumed.
+// The NHWC head of one scale is a row-major matrix [B * rows_img][K], K = C + 5,
+// one row per box.  A workgroup walks tiles of whole rows of one image.  A tile
+// (up to 32 KiB) goes from HBM straight into LDS with LDS-DMA loads
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination,
+// no VALU work), issued back to back so that the whole tile is in flight at
+// once; the 16-byte phase of the tile start is absorbed by an aligned window
+// plus a dword shift inside LDS.
 //
-// Detect mode never materialises the [N][C] confidence matrix.  A class logit x
-// can only reach conf = sigmoid(x) * sigmoid(obj) >= thr if sigmoid(x) >= thr,
-// so phase 1 is one compare per element against a conservatively lowered
-// logit(thr); the channel of an element is tracked incrementally (no division).
-// Survivors (about one per box) are staged in LDS as flat indices.  Phase 2
-// gives each staged element to a lane: load the row's objectness, evaluate the
-// exact confidence, compare with the threshold, decode and store the box,
-// stage the candidate key; one global atomic per workgroup then reserves the
-// range in the image's candidate list.
+// The tile is then consumed row-wise from LDS (row pitch K dwords; lanes on
+// consecutive rows or consecutive channels hit distinct banks):
+//   A. one lane per row reads the objectness logit; since
+//      conf = sigmoid(x) * sigmoid(obj) <= min(sigmoid(x), sigmoid(obj)),
+//      a row whose objectness is below a conservatively lowered logit(thr)
+//      cannot yield a candidate and is dropped with a single compare;
+//   B. the surviving rows' class logits are spread over all lanes; those that
+//      pass the same prefilter get the exact sigmoid product and threshold, and
+//      real candidates decode their box from the tile and stage a key.
+// The [N][C] confidence matrix is never materialised and nothing is read
+// twice from memory.  One global atomic per workgroup reserves the range in
+// the image's candidate list; the launch is oversubscribed (a few thousand
+// short workgroups) so that this latency-bound tail overlaps other workgroups'
+// streaming.
 #include "yh_internal.h"
 
 namespace yh {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 8;
-constexpr int kPreStage = 4096;  // phase-1 survivors staged per workgroup (flat indices)
-constexpr int kStage = 1024;     // candidate keys staged per workgroup
+constexpr int kStage = 512;      // candidate keys staged per workgroup
 
-static_assert(kThreads * kUnroll == (int)kStreamSlotGranule, "slot granule");
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 struct Stage {
+    float tile[kTileFloats];
     unsigned long long keys[kStage];
-    uint32_t pre[kPreStage];
-    int pre_count;
+    uint16_t rows[kTileFloats / 6 + 1];   // rows that passed step A (K >= 6)
+    int nrows;
     int count;
     int base;
 };
@@ -50,16 +56,17 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
 
 // Box of row `row` (YOLOv3.py:340-348): yx = cell + 0.5 + sigmoid(t_yx),
 // hw = prior + exp(t_hw), corners scaled by the per-scale multiplier.
-__device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, const float *t, uint32_t row)
+__device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float ty, float tx, float th,
+                                             float tw, uint32_t row)
 {
     const uint32_t cell = row / (uint32_t)P;
     const uint32_t pi = row - cell * (uint32_t)P;
     const uint32_t gy = cell / sc.grid_w;
     const uint32_t gx = cell - gy * sc.grid_w;
-    const float by = ((float)gy + 0.5f) + sigmoidf(t[0]);
-    const float bx = ((float)gx + 0.5f) + sigmoidf(t[1]);
-    const float bh = sc.prior_hw[pi][0] + expf(t[2]);
-    const float bw = sc.prior_hw[pi][1] + expf(t[3]);
+    const float by = ((float)gy + 0.5f) + sigmoidf(ty);
+    const float bx = ((float)gx + 0.5f) + sigmoidf(tx);
+    const float bh = sc.prior_hw[pi][0] + expf(th);
+    const float bw = sc.prior_hw[pi][1] + expf(tw);
     const float m = sc.mult;
     float4 o;
     o.x = (by - bh / 2.0f) * m;
@@ -69,44 +76,32 @@ __device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, const
     return o;
 }
 
-// Exact evaluation of one element (flat index l inside the image's span).
-template <int MODE>
-__device__ __forceinline__ void evaluate(Stage &st, const StreamParams &p, const StreamScale &sc,
-                                         const float *img, int b, uint32_t l)
+// Appends the staged candidate keys to the image's list: one global atomic per
+// call reserves the range.  Called by every thread of the workgroup.
+__device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &p, int b)
 {
-    const uint32_t K = (uint32_t)p.K, C = (uint32_t)p.C;
-    const uint32_t row = __umulhi(l, p.magic_k);          // l / K, exact for l * K < 2^32
-    const uint32_t k = l - row * K;
-    if (k >= C) return;
-    const float x = img[l];
-    const int n = (int)(sc.row_base + row);
-    if (MODE == kModeConf) {                               // the stream is the confidence matrix itself
-        if (x >= p.thr) push_candidate(st, p, b, make_key((int)k, x, n));
-        return;
+    const int tid = threadIdx.x;
+    const int cnt = st.count < kStage ? st.count : kStage;   // same value in every thread (read after a barrier)
+    if (cnt > 0) {
+        if (tid == 0) st.base = atomicAdd(&p.img_count[b], cnt);
+        __syncthreads();
+        const int base = st.base;
+        for (int i = tid; i < cnt; i += kThreads) {
+            const int g = base + i;
+            if (g < p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
+        }
+        __syncthreads();
+        if (tid == 0) st.count = 0;
+        __syncthreads();
     }
-    const float *rowp = img + (size_t)row * K;
-    const float cf = sigmoidf(x) * sigmoidf(rowp[C + 4]);
-    if (cf >= p.thr) {
-        reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] = decode_box(p.P, sc, rowp + C, row);
-        push_candidate(st, p, b, make_key((int)k, cf, n));
-    }
-}
-
-// Phase-1 survivor: remember its flat index.  Overflow is detected after the
-// loop (pre_count > kPreStage) and handled by re-walking the chunk.
-__device__ __forceinline__ void stage_survivor(Stage &st, uint32_t l)
-{
-    const int slot = atomicAdd(&st.pre_count, 1);
-    if (slot < kPreStage) st.pre[slot] = l;
 }
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 {
-    __shared__ Stage st;
-    const int tid = threadIdx.x;
-    if (tid == 0) { st.count = 0; st.pre_count = 0; }
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) Stage st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { st.count = 0; st.nrows = 0; }
 
     int s = 0;
 #pragma unroll
@@ -117,91 +112,81 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     const int b = (int)(r / sc.chunks_per_img);
     const uint32_t chunk = r - (uint32_t)b * sc.chunks_per_img;
 
-    const int K = p.K, C = p.C;
-    const uint32_t span = sc.span;
-    const long long s0 = (long long)b * span;              // first float of this image at this scale
-    const float *img = sc.src + s0;
-    // slots that lie completely inside the image: [q_lo_img, q_hi_img)
-    const long long q_lo_img = (s0 + 3) >> 2;
-    const long long q_hi_img = (s0 + span) >> 2;
-    long long q_lo = q_lo_img + (long long)chunk * p.chunk_slots;
-    long long q_hi = q_lo + p.chunk_slots;
-    if (q_hi > q_hi_img) q_hi = q_hi_img;
+    const int K = p.K, C = p.C, R = p.tile_rows;
+    const long long s0 = (long long)b * sc.span;            // first float of this image at this scale
+    const long long total = (long long)p.B * sc.span;       // floats in the tensor
+    const long long q_last = (total >> 2) - 1;              // last slot that lies completely inside the tensor
+    const float4 *src4 = reinterpret_cast<const float4 *>(sc.src);
     const float pf = (MODE == kModeConf) ? p.thr : p.prefilter;
 
-    if (q_lo < q_hi) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(sc.src) + q_lo;
-        const int nslots = (int)(q_hi - q_lo);              // <= chunk_slots
-        // channel of this lane's first element, then advanced by 1024 floats per load
-        const uint32_t l_first = (uint32_t)(q_lo * 4 - s0) + 4u * (uint32_t)tid;
-        int k = (int)(l_first - __umulhi(l_first, p.magic_k) * (uint32_t)K);
-        const int dk = (4 * kThreads) % K;
-        for (int it = 0; it < nslots; it += kThreads * kUnroll) {
-            float4 v[kUnroll];
+    const uint32_t row_begin = chunk * sc.tiles_per_chunk * (uint32_t)R;
+    uint32_t row_end = row_begin + sc.tiles_per_chunk * (uint32_t)R;
+    if (row_end > sc.rows_img) row_end = sc.rows_img;
+
+    for (uint32_t row_t = row_begin; row_t < row_end; row_t += (uint32_t)R) {
+        const int rows_t = (int)((row_end - row_t) < (uint32_t)R ? (row_end - row_t) : (uint32_t)R);
+        const long long f0 = s0 + (long long)row_t * K;      // first float of the tile
+        const long long q0 = f0 >> 2;                         // aligned window start (slots)
+        const int sh = (int)(f0 & 3);                         // dword shift of the tile inside the window
+        const int wslots = (sh + rows_t * K + 3) >> 2;       // window slots, <= kTileFloats / 4
+        // ---- HBM -> LDS, whole tile in flight
+        __syncthreads();                                      // previous tile fully consumed
+        long long nd = q_last - q0 + 1;                       // slots of the window that may be read as 16 bytes
+        const int ndma = nd < wslots ? (int)(nd < 0 ? 0 : nd) : wslots;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                int i = it + u * kThreads + tid;
-                i = i < nslots ? i : nslots - 1;            // clamped: the load is unconditional
-                v[u] = src4[i];
+        for (int j = 0; j < kTileFloats / 4 / kThreads; ++j) {
+            const int slot0 = (j * (kThreads / 64) + wave) * 64;
+            if (slot0 < ndma) {
+                int slot = slot0 + lane;
+                slot = slot < ndma ? slot : ndma - 1;        // lanes past the end re-read the last slot
+                __builtin_amdgcn_global_load_lds((gptr_t *)(src4 + q0 + slot), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int i = it + u * kThreads + tid;
-                const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                if (i < nslots && fmaxf(fmaxf(xs[0], xs[1]), fmaxf(xs[2], xs[3])) >= pf) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int kk = k + j;
-                        kk = kk >= K ? kk - K : kk;
-                        if (kk < C && xs[j] >= pf)
-                            stage_survivor(st, l_first + 4u * (uint32_t)(it + u * kThreads) + j);
-                    }
+        }
+        if (ndma < wslots) {                                  // the tensor's last, partial slot: 1..3 floats
+            const int left = (int)(total - (q0 + ndma) * 4);
+            if (tid < left) st.tile[ndma * 4 + tid] = sc.src[(q0 + ndma) * 4 + tid];
+        }
+        __syncthreads();                                      // waits for the DMA (vmcnt) and publishes the tile
+        const float *tile = st.tile + sh;
+
+        // ---- A: rows whose objectness can still reach the threshold
+        int nrows;
+        if (MODE == kModeDetect) {
+            for (int rr = tid; rr < rows_t; rr += kThreads) {
+                if (tile[rr * K + C + 4] >= pf) st.rows[atomicAdd(&st.nrows, 1)] = (uint16_t)rr;
+            }
+            __syncthreads();
+            nrows = st.nrows;
+        } else {
+            nrows = rows_t;
+        }
+        // ---- B: class logits of those rows, spread over all lanes
+        const int items = nrows * C;
+        for (int item = tid; item < items; item += kThreads) {
+            const int ri = item / C, c = item - ri * C;
+            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+            const float *rp = tile + rr * K;
+            const float x = rp[c];
+            if (!(x >= pf)) continue;
+            const uint32_t row = row_t + (uint32_t)rr;
+            const int n = (int)(sc.row_base + row);
+            if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
+                push_candidate(st, p, b, make_key(c, x, n));
+            } else {
+                const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
+                if (cf >= p.thr) {
+                    reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
+                        decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
+                    push_candidate(st, p, b, make_key(c, cf, n));
                 }
-                k += dk;
-                k = k >= K ? k - K : k;
             }
         }
-    }
-    // the (up to 3 + 3) elements of the image that share a slot with a neighbour
-    // image are evaluated directly
-    if (chunk == 0) {
-        const uint32_t head_n = (uint32_t)(q_lo_img * 4 - s0);
-        const uint32_t tail_n = (uint32_t)((s0 + span) - q_hi_img * 4);
-        uint32_t l = 0xffffffffu;
-        if (q_lo_img <= q_hi_img) {
-            if ((uint32_t)tid < head_n) l = tid;
-            else if ((uint32_t)tid >= 32u && (uint32_t)tid - 32u < tail_n) l = span - tail_n + ((uint32_t)tid - 32u);
-        } else if ((uint32_t)tid < span) {                   // image smaller than one slot
-            l = tid;
-        }
-        if (l != 0xffffffffu && img[l] >= pf) evaluate<MODE>(st, p, sc, img, b, l);
-    }
-
-    // phase 2: exact evaluation of the staged survivors, one per lane
-    __syncthreads();
-    const int npre = st.pre_count;
-    if (npre <= kPreStage) {
-        for (int i = tid; i < npre; i += kThreads) evaluate<MODE>(st, p, sc, img, b, st.pre[i]);
-    } else if (q_lo < q_hi) {
-        // more survivors than the staging area holds (very low thresholds):
-        // walk the chunk again, element by element, from the cache
-        const uint32_t l0 = (uint32_t)(q_lo * 4 - s0);
-        const uint32_t nel = 4u * (uint32_t)(q_hi - q_lo);
-        for (uint32_t i = tid; i < nel; i += kThreads)
-            if (img[l0 + i] >= pf) evaluate<MODE>(st, p, sc, img, b, l0 + i);
-    }
-
-    __syncthreads();
-    const int cnt = st.count < kStage ? st.count : kStage;
-    if (cnt > 0) {
-        if (tid == 0) st.base = atomicAdd(&p.img_count[b], cnt);
         __syncthreads();
-        const int base = st.base;
-        for (int i = tid; i < cnt; i += kThreads) {
-            const int g = base + i;
-            if (g < p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
-        }
+        if (tid == 0) st.nrows = 0;
+        if (st.count >= kStage / 2) flush_candidates(st, p, b);
     }
+    __syncthreads();
+    flush_candidates(st, p, b);
 }
 
 // Full decode (yh_decode): boxes [B][N][4] and, optionally, conf [B][N][C].
@@ -221,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void k_decode_full(const StreamParams p, 
     if (k < C) {
         if (p.conf) p.conf[n * C + k] = sigmoidf(img[l]) * sigmoidf(img[(size_t)row * K + C + 4]);
     } else if (k == C) {
-        reinterpret_cast<float4 *>(p.boxes)[n] = decode_box(p.P, sc, img + l, row);
+        reinterpret_cast<float4 *>(p.boxes)[n] = decode_box(p.P, sc, img[l], img[l + 1], img[l + 2], img[l + 3], row);
     }
 }
 

@@ -154,6 +154,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if w['kind'] == 'detect':
+        hd.detect(sets[0], w['thr'], w['iou'], w['max_boxes']).resolved()   # settles the candidate capacity (untimed)
     last = None
     for i in range(warmup):
         last = step(i)

@@ -85,7 +85,14 @@ int yh_boxes_per_image(const yh_head_config *cfg, int64_t *n);
 int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batch,
               float *boxes, float *conf, void *stream);
 
-/* Workspace size (host out) for yh_detect / yh_nms with these bounds. */
+/* Workspace size (host out) for yh_detect with these bounds.
+ * The workspace of yh_detect / yh_nms must be ZERO-FILLED once after it is
+ * allocated (hipMemset); every call leaves it in a state the next call, with
+ * the same arguments to the size query, can start from.  A workspace must not
+ * be shared by calls that overlap in time.
+ * max_candidates <= 4096 (with num_classes <= 1024 and nms_max_boxes <= 128)
+ * selects a single-launch form of the candidates -> detections stage; larger
+ * capacities take a three-launch form.  Results are identical. */
 int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
                               int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);
 

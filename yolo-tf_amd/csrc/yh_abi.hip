@@ -316,8 +316,7 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e = yh::launch_reset(w.img_count, batch, status, st);
-    if (e != hipSuccess) return hip_fail(e, "reset launch");
+    hipError_t e;
 
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, heads, batch);
@@ -326,6 +325,7 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     p.cand_cap = max_candidates;
     p.cand = w.cand;
     p.img_count = w.img_count;
+    p.status = status;
     p.boxes = w.boxes;
     const uint32_t blocks = plan_stream(p, batch);
     if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return hip_fail(e, "event record");
@@ -390,8 +390,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e = yh::launch_reset(w.img_count, batch, status, st);
-    if (e != hipSuccess) return hip_fail(e, "reset launch");
+    hipError_t e;
 
     // the confidence matrix is streamed as a one-scale "head" whose rows hold C channels
     yh::StreamParams p;
@@ -402,6 +401,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     p.cand_cap = max_candidates;
     p.cand = w.cand;
     p.img_count = w.img_count;
+    p.status = status;
     p.sc[0].src = conf;
     p.sc[0].rows_img = (uint32_t)boxes_per_img;
     p.sc[0].span = (uint32_t)(boxes_per_img * num_classes);

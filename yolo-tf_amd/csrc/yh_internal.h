@@ -65,7 +65,8 @@ struct StreamParams {
     float prefilter;        // logits below this cannot reach thr
     int32_t cand_cap;
     unsigned long long *cand;   // [B][cand_cap]
-    int32_t *img_count;         // [B]
+    int32_t *img_count;         // [B], zero on entry; the kernel that consumes it zeroes it again
+    int32_t *status;            // [1] device status word, zeroed by the streaming pass
     float *boxes;               // [B][N][4]
     float *conf;                // [B][N][C] (full decode only, may be null)
     StreamScale sc[YH_MAX_SCALES];
@@ -85,7 +86,7 @@ struct NmsParams {
     float iou_thr;
     const unsigned long long *cand;    // [B][cand_cap] unordered
     unsigned long long *seg_keys;      // [B][cand_cap] binned by class, then sorted
-    const int32_t *img_count;          // [B]
+    int32_t *img_count;                // [B]; zeroed again once consumed
     int32_t *seg_off;                  // [B][C]
     int32_t *seg_cnt;                  // [B][C]
     int32_t *kept_cnt;                 // [B][C]
@@ -101,9 +102,13 @@ struct NmsParams {
     int32_t *status;
 };
 
+// single-launch shape of the candidates -> detections stage (k_post)
+constexpr int kPostCap = 4096;          // candidates per image
+constexpr int kPostRankMax = 1024;      // up to here: rank sort; above: bitonic
+constexpr int kPostMaxClasses = 1024;
+constexpr int kPostMaxBoxes = 128;
+
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
-// zeroes the per-image candidate counters and the status word (one launch)
-hipError_t launch_reset(int32_t *img_count, int32_t batch, int32_t *status, hipStream_t st);
 
 // ---- loss ------------------------------------------------------------------
 struct LossScale {

@@ -59,13 +59,14 @@ class Detections:
         return bool(int(self.status.item()) & _abi.YH_STATUS_CANDIDATE_OVERFLOW)
 
     def resolved(self):
-        """Synchronises; if the candidate capacity overflowed, reruns with the
-        worst-case capacity and returns the rerun's result."""
-        if self.overflowed():
-            if self._rerun is None:
+        """Synchronises; while the candidate capacity overflows, reruns with a
+        16x larger one (up to the worst case N*C) and returns the final result."""
+        r = self
+        while r.overflowed():
+            if r._rerun is None:
                 raise RuntimeError('candidate capacity overflow; raise max_candidates')
-            return self._rerun()
-        return self
+            r = r._rerun()
+        return r
 
     def per_image(self):
         """[(scores [K], bbox [K,4], class_id [K], index [K])] as NumPy arrays,
@@ -93,6 +94,7 @@ class DetectionHead:
         self.gt_rate = [float(r) for r in gt_rate]
         self._ws = {}
         self._plans = {}
+        self._grown = {}
 
     # ------------------------------------------------------------ helpers
     def _check_heads(self, heads):
@@ -122,7 +124,8 @@ class DetectionHead:
     def _workspace(self, key, nbytes, device):
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes or ws.device != device:
-            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            # zero-filled once: the library keeps its counters clean from call to call
+            ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._ws[key] = ws
         return ws
 
@@ -146,9 +149,14 @@ class DetectionHead:
         return boxes, conf
 
     # ------------------------------------------------------------- detect
+    SMALL_CAPACITY = 4096      # largest capacity of the single-launch candidates -> detections stage
+
     def default_max_candidates(self, N):
+        """Per-image candidate capacity used when the caller gives none: the
+        single-launch capacity, or whatever an earlier overflow on this head
+        geometry grew it to (Detections.resolved)."""
         full = N * self.num_classes
-        return int(min(full, max(4096, full // 16)))
+        return int(min(full, self._grown.get(N, self.SMALL_CAPACITY)))
 
     def _alloc_outputs(self, B, max_boxes, dev, want_class_candidates):
         C = self.num_classes
@@ -172,12 +180,13 @@ class DetectionHead:
         heads = self._check_heads(heads)
         dev = heads[0].device
         # geometry, capacity and workspace depend only on the shapes: planned once per shape
-        key = ('detect', tuple(tuple(h.shape) for h in heads), max_candidates, int(max_boxes), dev)
+        N = self.boxes_per_image(heads)
+        cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
+        key = ('detect', tuple(tuple(h.shape) for h in heads), cap, int(max_boxes), dev)
         plan = self._plans.get(key)
         if plan is None:
             cfg = self.config_for(heads)
-            B, N = heads[0].shape[0], self.boxes_per_image(heads)
-            cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
+            B = heads[0].shape[0]
             nbytes = ctypes.c_size_t(0)
             _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
             ws = self._workspace(('detect', B, N, cap, int(max_boxes)), nbytes.value, dev)
@@ -201,8 +210,11 @@ class DetectionHead:
         full = N * self.num_classes
         rerun = None
         if cap < full:
-            rerun = lambda: self.detect(heads, score_threshold, iou_threshold, max_boxes, full,
-                                        want_class_candidates)
+            def rerun():
+                grown = min(full, cap * 16)
+                if max_candidates is None:
+                    self._grown[N] = max(grown, self._grown.get(N, 0))
+                return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown, want_class_candidates)
         return Detections(count, scores, boxes, cls, idx, cc, status, rerun)
 
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
@@ -231,8 +243,11 @@ class DetectionHead:
                                   status.data_ptr(), self._stream(dev)))
         rerun = None
         if cap < full:
-            rerun = lambda: self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, full,
-                                     want_class_candidates)
+            def rerun():
+                grown = min(full, cap * 16)
+                if max_candidates is None:
+                    self._grown[N] = max(grown, self._grown.get(N, 0))
+                return self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, grown, want_class_candidates)
         return Detections(count, scores, oboxes, cls, idx, cc, status, rerun)
 
     # --------------------------------------------------------------- loss

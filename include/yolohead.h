@@ -90,8 +90,8 @@ int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batc
  * allocated (hipMemset); every call leaves it in a state the next call, with
  * the same arguments to the size query, can start from.  A workspace must not
  * be shared by calls that overlap in time.
- * max_candidates <= 4096 (with num_classes <= 1024 and nms_max_boxes <= 128)
- * selects a single-launch form of the candidates -> detections stage; larger
+ * max_candidates <= 2048 (with num_classes <= 1024, nms_max_boxes <= 128 and
+ * num_classes * nms_max_boxes <= 4096) selects a single-launch form of the candidates -> detections stage; larger
  * capacities take a three-launch form.  Results are identical. */
 int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
                               int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);

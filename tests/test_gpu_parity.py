@@ -156,7 +156,7 @@ def test_detect_equals_decode_then_nms_at_full_size(gpu):
 
 
 def test_both_launch_shapes_agree(gpu, c_oracle):
-    """Capacity <= 4096 takes the single-launch candidates -> detections stage,
+    """Capacity <= 2048 takes the single-launch candidates -> detections stage,
     a larger one the three-launch stage: identical results, and the same
     workspace can be reused call after call."""
     case = cases.v3()
@@ -164,7 +164,7 @@ def test_both_launch_shapes_agree(gpu, c_oracle):
     dheads = to_dev(heads, gpu)
     hd = case.head_obj()
     want = c_oracle.nms(*[t.cpu().numpy() for t in hd.decode(dheads)], 0.5, 0.5, 10)
-    for cap in (4096, 4097, 4096, 100000):
+    for cap in (2048, 2049, 2048, 100000):
         for _ in range(2):
             got = hd.detect(dheads, 0.5, 0.5, 10, max_candidates=cap, want_class_candidates=True)
             assert not got.overflowed()

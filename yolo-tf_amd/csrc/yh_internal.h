@@ -103,10 +103,11 @@ struct NmsParams {
 };
 
 // single-launch shape of the candidates -> detections stage (k_post)
-constexpr int kPostCap = 4096;          // candidates per image
+constexpr int kPostCap = 2048;          // candidates per image
 constexpr int kPostRankMax = 1024;      // up to here: rank sort; above: bitonic
 constexpr int kPostMaxClasses = 1024;
 constexpr int kPostMaxBoxes = 128;
+constexpr int kPostKeptMax = 4096;      // num_classes * nms_max_boxes
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
 

@@ -15,9 +15,10 @@
 // Two launch shapes:
 //  * k_post, one workgroup per image, when an image holds at most kPostCap
 //    candidates (the capacity the caller passes): the whole list is sorted in
-//    LDS by the full key (class, score, row), the wavefronts take the class
-//    segments in turn and the same workgroup writes the concatenated outputs.
-//    One launch, no intermediate global traffic.
+//    LDS by the full key (class, score, row), the candidates' boxes are
+//    gathered into LDS in one go, the wavefronts take the class segments in
+//    turn and the same workgroup writes the concatenated outputs.  One launch,
+//    no intermediate global traffic.
 //  * k_bin -> k_sort_nms -> k_finalize for larger capacities: class histogram
 //    and scatter per image, then one workgroup per (image, class) segment.
 #include "yh_internal.h"
@@ -119,10 +120,16 @@ __device__ __forceinline__ bool suppresses(float ymin_i, float xmin_i, float yma
 
 // Greedy NMS of one sorted segment by ONE wavefront (all 64 lanes call it).
 // keys[0..cnt): sorted candidate keys (LDS or global); kbox: room for max_boxes
-// selected boxes (5 floats each) private to this wavefront; krow / kscore: the
-// segment's output lists.  Returns the number selected.
-__device__ int wave_nms(const unsigned long long *keys, int cnt, const float4 *boxes4, float (*kbox)[5],
-                        float thr, int max_boxes, int32_t *krow, float *kscore)
+// selected boxes (5 floats each) private to this wavefront.  Returns the number
+// selected.
+//   IN_LDS = false: boxes are gathered from boxes4[row]; the selection goes to
+//                   krow / kscore (global, one list per segment);
+//   IN_LDS = true : boxes_seg[i] is the box of keys[i] (LDS); the selection goes
+//                   to kpos as positions pos_base + i (LDS).
+template <bool IN_LDS>
+__device__ int wave_nms(const unsigned long long *keys, int cnt, const float4 *boxes4, const float4 *boxes_seg,
+                        float (*kbox)[5], float thr, int max_boxes, int32_t *krow, float *kscore,
+                        uint16_t *kpos, int pos_base)
 {
     const int lane = threadIdx.x & 63;
     int kept = 0;
@@ -131,7 +138,8 @@ __device__ int wave_nms(const unsigned long long *keys, int cnt, const float4 *b
         const bool valid = i < cnt;
         const unsigned long long key = valid ? keys[i] : 0ull;
         const int n = key_row(key);
-        const float4 bx = valid ? boxes4[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) bx = IN_LDS ? boxes_seg[i] : boxes4[n];
         const float ymin = fminf(bx.x, bx.z), xmin = fminf(bx.y, bx.w);
         const float ymax = fmaxf(bx.x, bx.z), xmax = fmaxf(bx.y, bx.w);
         const float area = (ymax - ymin) * (xmax - xmin);
@@ -169,8 +177,12 @@ __device__ int wave_nms(const unsigned long long *keys, int cnt, const float4 *b
             const int pos = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
             kbox[pos][0] = ymin; kbox[pos][1] = xmin; kbox[pos][2] = ymax; kbox[pos][3] = xmax;
             kbox[pos][4] = area;
-            krow[pos] = n;
-            kscore[pos] = key_score(key);
+            if (IN_LDS) {
+                kpos[pos] = (uint16_t)(pos_base + i);
+            } else {
+                krow[pos] = n;
+                kscore[pos] = key_score(key);
+            }
         }
         kept += __popcll(keepmask);
     }
@@ -202,18 +214,24 @@ __device__ void write_outputs(const NmsParams &p, int b, const int *s_off, const
 }
 
 // ------------------------------------------------------------------ k_post
-// One workgroup per image, capacity <= kPostCap candidates, C <= kPostMaxClasses,
-// max_boxes <= kPostMaxBoxes.  Dynamic LDS: (kPostThreads / 64) * max_boxes * 5 floats.
+// One workgroup per image, for capacity <= kPostCap candidates, C <=
+// kPostMaxClasses and C * max_boxes <= kPostKeptMax.  Everything between the
+// candidate list and the outputs stays in LDS: keys, the candidates' boxes
+// (gathered once, all loads in flight together), the selections.
+// Dynamic LDS: (kPostThreads / 64) * max_boxes * 5 floats.
 __global__ __launch_bounds__(kPostThreads) void k_post(const NmsParams p)
 {
     extern __shared__ __align__(16) float s_kbox_all[];
     __shared__ unsigned long long s_keys[kPostCap];
     __shared__ unsigned long long s_sorted[kPostRankMax];
-    __shared__ int s_off[kPostMaxClasses];
+    __shared__ float4 s_box[kPostCap];
+    __shared__ uint16_t s_kpos[kPostKeptMax];
+    __shared__ int s_off[kPostMaxClasses];      // segment offsets, later output offsets
+    __shared__ int s_seg[kPostMaxClasses];      // segment offsets (kept)
     __shared__ int s_cnt[kPostMaxClasses];
     __shared__ int s_kept[kPostMaxClasses];
     __shared__ int s_wave[kPostThreads / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, C = p.C;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, C = p.C, mb = p.max_boxes;
 
     const int raw = p.img_count[b];
     const int M = raw < p.cand_cap ? raw : p.cand_cap;
@@ -247,6 +265,9 @@ __global__ __launch_bounds__(kPostThreads) void k_post(const NmsParams p)
         bitonic_sort<kPostThreads>(s_keys, M, n2);
         sorted = s_keys;
     }
+    // every candidate's box, one gather with all loads in flight
+    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+    for (int i = tid; i < M; i += kPostThreads) s_box[i] = boxes4[key_row(sorted[i])];
     for (int c = tid; c < C; c += kPostThreads) {
         const int n = s_cnt[c];
         s_off[c] = n;
@@ -254,23 +275,38 @@ __global__ __launch_bounds__(kPostThreads) void k_post(const NmsParams p)
     }
     __syncthreads();
     block_exclusive_scan<kPostThreads, kPostMaxClasses / kPostThreads>(s_off, C, s_wave);
+    for (int c = tid; c < C; c += kPostThreads) s_seg[c] = s_off[c];
+    __syncthreads();
 
     // the wavefronts take the non-empty class segments in turn
-    float (*kbox)[5] = reinterpret_cast<float (*)[5]>(s_kbox_all + (size_t)wave * p.max_boxes * 5);
-    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+    float (*kbox)[5] = reinterpret_cast<float (*)[5]>(s_kbox_all + (size_t)wave * mb * 5);
     for (int c = wave; c < C; c += kPostThreads / 64) {
         const int cnt = s_cnt[c];
         if (cnt == 0) continue;
-        const long long seg = (long long)b * C + c;
-        const int kept = wave_nms(sorted + s_off[c], cnt, boxes4, kbox, p.iou_thr, p.max_boxes,
-                                  p.kept_row + seg * p.max_boxes, p.kept_score + seg * p.max_boxes);
+        const int off = s_seg[c];
+        const int kept = wave_nms<true>(sorted + off, cnt, nullptr, s_box + off, kbox, p.iou_thr, mb,
+                                        nullptr, nullptr, s_kpos + c * mb, off);
         if ((tid & 63) == 0) s_kept[c] = kept;
     }
-    __syncthreads();                                          // kept lists (global) and counts visible to the workgroup
+    __syncthreads();
     for (int c = tid; c < C; c += kPostThreads) s_off[c] = s_kept[c];
     __syncthreads();
     block_exclusive_scan<kPostThreads, kPostMaxClasses / kPostThreads>(s_off, C, s_wave);
-    write_outputs<kPostThreads>(p, b, s_off, s_kept);
+    // concatenation of the classes' selections (YOLOv3.py:362-367)
+    const int cap = C * mb;
+    for (int e = tid; e < cap; e += kPostThreads) {
+        const int c = e / mb, j = e - c * mb;
+        if (j < s_kept[c]) {
+            const int pos = s_kpos[e];
+            const unsigned long long key = sorted[pos];
+            const long long dst = (long long)b * cap + s_off[c] + j;
+            p.out_scores[dst] = key_score(key);
+            reinterpret_cast<float4 *>(p.out_boxes)[dst] = s_box[pos];
+            p.out_class[dst] = c;
+            p.out_index[dst] = key_row(key);
+        }
+    }
+    if (tid == 0) p.out_count[b] = s_off[C - 1] + s_kept[C - 1];
 }
 
 // ------------------------------------------------ general path: bin, sort+nms, finalize
@@ -355,9 +391,10 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     }
     __syncthreads();          // sorted keys in global memory, visible to wave 0
     if (tid >= 64) return;
-    const int kept = wave_nms(keys, cnt, reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N, s_kbox,
-                              p.iou_thr, p.max_boxes, p.kept_row + (long long)seg * p.max_boxes,
-                              p.kept_score + (long long)seg * p.max_boxes);
+    const int kept = wave_nms<false>(keys, cnt, reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N,
+                                     nullptr, s_kbox, p.iou_thr, p.max_boxes,
+                                     p.kept_row + (long long)seg * p.max_boxes,
+                                     p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
     if (tid == 0) p.kept_cnt[seg] = kept;
 }
 
@@ -376,7 +413,8 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p)
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;
-    if (p.cand_cap <= kPostCap && p.C <= kPostMaxClasses && p.max_boxes <= kPostMaxBoxes) {
+    if (p.cand_cap <= kPostCap && p.C <= kPostMaxClasses && p.max_boxes <= kPostMaxBoxes &&
+        p.C * p.max_boxes <= kPostKeptMax) {
         const size_t lds = (size_t)(kPostThreads / 64) * p.max_boxes * 5 * sizeof(float);
         hipLaunchKernelGGL(k_post, dim3(p.B), dim3(kPostThreads), lds, stm, p);
         return hipGetLastError();

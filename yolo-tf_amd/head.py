@@ -149,7 +149,7 @@ class DetectionHead:
         return boxes, conf
 
     # ------------------------------------------------------------- detect
-    SMALL_CAPACITY = 4096      # largest capacity of the single-launch candidates -> detections stage
+    SMALL_CAPACITY = 2048      # largest capacity of the single-launch candidates -> detections stage
 
     def default_max_candidates(self, N):
         """Per-image candidate capacity used when the caller gives none: the

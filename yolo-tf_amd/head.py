@@ -171,7 +171,7 @@ class DetectionHead:
         return count, scores, boxes, cls, idx, cc, status
 
     def detect(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-               want_class_candidates=False, outputs=None, stream_events=None):
+               want_class_candidates=False, outputs=None, stream_events=None, _auto=False):
         """Decode + score filter + per-class NMS for every image (YOLOv3.py:320-368).
         Enqueues on the current stream and returns device tensors; nothing
         synchronises until the result is read.  outputs: a tuple from
@@ -210,15 +210,18 @@ class DetectionHead:
         full = N * self.num_classes
         rerun = None
         if cap < full:
+            auto = _auto or max_candidates is None
+
             def rerun():
                 grown = min(full, cap * 16)
-                if max_candidates is None:
+                if auto:                                    # remembered for later calls on this geometry
                     self._grown[N] = max(grown, self._grown.get(N, 0))
-                return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown, want_class_candidates)
+                return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown,
+                                   want_class_candidates, _auto=auto)
         return Detections(count, scores, boxes, cls, idx, cc, status, rerun)
 
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-            want_class_candidates=False):
+            want_class_candidates=False, _auto=False):
         """Score filter + per-class NMS on decoded inputs (YOLOv3.py:351-368).
         boxes [B,N,4], conf [B,N,C] float32 CUDA tensors."""
         lib = _abi.load()
@@ -243,11 +246,14 @@ class DetectionHead:
                                   status.data_ptr(), self._stream(dev)))
         rerun = None
         if cap < full:
+            auto = _auto or max_candidates is None
+
             def rerun():
                 grown = min(full, cap * 16)
-                if max_candidates is None:
+                if auto:
                     self._grown[N] = max(grown, self._grown.get(N, 0))
-                return self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, grown, want_class_candidates)
+                return self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, grown,
+                                want_class_candidates, _auto=auto)
         return Detections(count, scores, oboxes, cls, idx, cc, status, rerun)
 
     # --------------------------------------------------------------- loss

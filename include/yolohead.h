@@ -47,7 +47,7 @@ typedef enum yh_status {
     YH_ERR_ALIGN = -6
 } yh_status;
 
-/* bits of the device-side status word written by yh_detect / yh_nms */
+/* bits of the per-image device-side status words written by yh_detect / yh_nms */
 #define YH_STATUS_CANDIDATE_OVERFLOW 1 /* an image had more candidates than max_candidates; result invalid for it */
 
 /* Geometry of the head, the data that distinguishes YOLOv3 from YOLOv2:
@@ -109,7 +109,7 @@ int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
  *   out_index   [B][C*nms_max_boxes]      box row n of each detection;
  *   out_class_candidates [B][C]           per-class count after the score
  *                                         filter (YOLOv3.py:356); may be NULL;
- *   status      [1]                       device status word, zeroed by the call.
+ *   status      [B]                       per-image status word, written by the call.
  * Equal scores inside a class are taken in ascending box row. */
 int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
               float score_threshold, float iou_threshold, int32_t nms_max_boxes,

@@ -156,15 +156,16 @@ def test_detect_equals_decode_then_nms_at_full_size(gpu):
 
 
 def test_both_launch_shapes_agree(gpu, c_oracle):
-    """Capacity <= 2048 takes the single-launch candidates -> detections stage,
+    """Capacity <= 512 finishes inside the streaming kernel, <= 2048 takes the
+    single-launch candidates -> detections stage,
     a larger one the three-launch stage: identical results, and the same
     workspace can be reused call after call."""
     case = cases.v3()
-    heads = case.heads(55, 3, obj_mean=-2.0)
+    heads = case.heads(55, 3)
     dheads = to_dev(heads, gpu)
     hd = case.head_obj()
     want = c_oracle.nms(*[t.cpu().numpy() for t in hd.decode(dheads)], 0.5, 0.5, 10)
-    for cap in (2048, 2049, 2048, 100000):
+    for cap in (512, 513, 2048, 2049, 512, 100000):
         for _ in range(2):
             got = hd.detect(dheads, 0.5, 0.5, 10, max_candidates=cap, want_class_candidates=True)
             assert not got.overflowed()

@@ -104,7 +104,8 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     char *p = static_cast<char *>(base);
     const size_t o_cand = take((size_t)B * cap * 8), o_seg = take((size_t)B * cap * 8);
     const size_t o_box = with_boxes ? take((size_t)B * N * 16) : 0;
-    const size_t o_img = take((size_t)B * 4), o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
+    const size_t o_img = take((size_t)B * 4);
+    const size_t o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
     const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
     w.cand = reinterpret_cast<unsigned long long *>(p + o_cand);
     w.seg_keys = reinterpret_cast<unsigned long long *>(p + o_seg);
@@ -274,10 +275,10 @@ int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_img, int32_t num_cla
     return YH_OK;
 }
 
-static int run_nms_stage(const DetectWs &w, int32_t B, int32_t C, int32_t N, const float *boxes,
+static yh::NmsParams make_nms_params(const DetectWs &w, int32_t B, int32_t C, int32_t N, const float *boxes,
                          float iou_thr, int32_t max_boxes, int32_t max_cand,
                          int32_t *out_count, float *out_scores, float *out_boxes, int32_t *out_class,
-                         int32_t *out_index, int32_t *out_class_candidates, int32_t *status, hipStream_t st)
+                         int32_t *out_index, int32_t *out_class_candidates, int32_t *status)
 {
     yh::NmsParams q;
     std::memset(&q, 0, sizeof(q));
@@ -288,7 +289,20 @@ static int run_nms_stage(const DetectWs &w, int32_t B, int32_t C, int32_t N, con
     q.out_count = out_count; q.out_scores = out_scores; q.out_boxes = out_boxes;
     q.out_class = out_class; q.out_index = out_index; q.out_class_candidates = out_class_candidates;
     q.status = status;
-    const hipError_t e = yh::launch_nms_pipeline(q, st);
+    return q;
+}
+
+// Streaming pass, then the candidates -> detections stage.
+static int run_pipeline(yh::StreamParams &p, yh::StreamMode mode, const yh::NmsParams &q,
+                        int32_t batch, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    const uint32_t blocks = plan_stream(p, batch);
+    hipError_t e;
+    if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return hip_fail(e, "event record");
+    e = yh::launch_stream(p, mode, blocks, st);
+    if (e != hipSuccess) return hip_fail(e, "stream launch");
+    if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return hip_fail(e, "event record");
+    e = yh::launch_nms_pipeline(q, st);
     if (e != hipSuccess) return hip_fail(e, "nms launch");
     return YH_OK;
 }
@@ -316,8 +330,6 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e;
-
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, heads, batch);
     p.thr = score_threshold;
@@ -325,16 +337,11 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     p.cand_cap = max_candidates;
     p.cand = w.cand;
     p.img_count = w.img_count;
-    p.status = status;
     p.boxes = w.boxes;
-    const uint32_t blocks = plan_stream(p, batch);
-    if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return hip_fail(e, "event record");
-    e = yh::launch_stream(p, yh::kModeDetect, blocks, st);
-    if (e != hipSuccess) return hip_fail(e, "detect stream launch");
-    if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return hip_fail(e, "event record");
-    return run_nms_stage(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold, nms_max_boxes,
-                         max_candidates, out_count, out_scores, out_boxes, out_class, out_index,
-                         out_class_candidates, status, st);
+    const yh::NmsParams q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
+                                            nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
+                                            out_class, out_index, out_class_candidates, status);
+    return run_pipeline(p, yh::kModeDetect, q, batch, st, ev_begin, ev_end);
 }
 
 int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
@@ -390,7 +397,6 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    hipError_t e;
 
     // the confidence matrix is streamed as a one-scale "head" whose rows hold C channels
     yh::StreamParams p;
@@ -401,17 +407,14 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     p.cand_cap = max_candidates;
     p.cand = w.cand;
     p.img_count = w.img_count;
-    p.status = status;
     p.sc[0].src = conf;
     p.sc[0].rows_img = (uint32_t)boxes_per_img;
     p.sc[0].span = (uint32_t)(boxes_per_img * num_classes);
     p.sc[0].grid_w = 1;
-    const uint32_t blocks = plan_stream(p, batch);
-    e = yh::launch_stream(p, yh::kModeConf, blocks, st);
-    if (e != hipSuccess) return hip_fail(e, "conf stream launch");
-    return run_nms_stage(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold, nms_max_boxes,
-                         max_candidates, out_count, out_scores, out_boxes, out_class, out_index,
-                         out_class_candidates, status, st);
+    const yh::NmsParams q = make_nms_params(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold,
+                                            nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
+                                            out_class, out_index, out_class_candidates, status);
+    return run_pipeline(p, yh::kModeConf, q, batch, st, nullptr, nullptr);
 }
 
 static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batch, int32_t pad)

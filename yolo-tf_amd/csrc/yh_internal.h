@@ -50,7 +50,7 @@ struct StreamScale {
     uint32_t span;          // rows_img * K floats
     uint32_t grid_w;
     uint32_t row_base;      // first box row of this scale inside an image
-    uint32_t blk_begin;     // first block of this scale
+    uint32_t blk_begin;     // first workgroup of this scale inside an image's run of workgroups
     uint32_t chunks_per_img;
     uint32_t tiles_per_chunk;   // tiles one workgroup walks
     float mult;
@@ -66,7 +66,6 @@ struct StreamParams {
     int32_t cand_cap;
     unsigned long long *cand;   // [B][cand_cap]
     int32_t *img_count;         // [B], zero on entry; the kernel that consumes it zeroes it again
-    int32_t *status;            // [1] device status word, zeroed by the streaming pass
     float *boxes;               // [B][N][4]
     float *conf;                // [B][N][C] (full decode only, may be null)
     StreamScale sc[YH_MAX_SCALES];

@@ -101,10 +101,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 {
     __shared__ __attribute__((aligned(16))) Stage st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        st.count = 0; st.nrows = 0;
-        if (blockIdx.x == 0) *p.status = 0;                    // later kernels of the call OR their flags into it
-    }
+    if (tid == 0) { st.count = 0; st.nrows = 0; }
 
     int s = 0;
 #pragma unroll

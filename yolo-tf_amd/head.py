@@ -51,12 +51,14 @@ class Detections:
         self.class_id = class_id            # [B, C*max_boxes] int32
         self.index = index                  # [B, C*max_boxes] int32: box row of each detection
         self.class_candidates = class_candidates   # [B, C] int32 or None
-        self.status = status                # [1] int32 device status word
+        self.status = status                # [B] int32 per-image device status words
         self._rerun = rerun
 
     def overflowed(self):
         """Synchronises and reports whether an image exceeded max_candidates."""
-        return bool(int(self.status.item()) & _abi.YH_STATUS_CANDIDATE_OVERFLOW)
+        if self.status.numel() == 0:
+            return False
+        return bool(int((self.status & _abi.YH_STATUS_CANDIDATE_OVERFLOW).max().item()))
 
     def resolved(self):
         """Synchronises; while the candidate capacity overflows, reruns with a
@@ -167,7 +169,7 @@ class DetectionHead:
         cls = torch.empty((B, cap), dtype=torch.int32, device=dev)
         idx = torch.empty((B, cap), dtype=torch.int32, device=dev)
         cc = torch.empty((B, C), dtype=torch.int32, device=dev) if want_class_candidates else None
-        status = torch.empty((1,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
         return count, scores, boxes, cls, idx, cc, status
 
     def detect(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates=None,

@@ -88,15 +88,17 @@ float prefilter_logit(float thr)
 }
 
 struct DetectWs {
-    unsigned long long *cand, *seg_keys;
-    float *boxes;
+    unsigned long long *cand, *seg_keys, *ukeys;
+    float *boxes, *cand_box, *uboxes;
     int32_t *img_count, *seg_off, *seg_cnt, *kept_cnt, *kept_row;
     float *kept_score;
     size_t bytes;
 };
 
-// with_boxes: the workspace also holds the decoded boxes [B][N][4]
-DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, int64_t mb, bool with_boxes)
+// with_boxes: the workspace also holds the decoded boxes [B][N][4] and the
+// slot-indexed candidate boxes; upi: work units per image with private slots
+DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, int64_t mb, bool with_boxes,
+                      int64_t upi)
 {
     DetectWs w;
     size_t off = 0;
@@ -104,6 +106,12 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     char *p = static_cast<char *>(base);
     const size_t o_cand = take((size_t)B * cap * 8), o_seg = take((size_t)B * cap * 8);
     const size_t o_box = with_boxes ? take((size_t)B * N * 16) : 0;
+    const size_t o_cbox = with_boxes ? take((size_t)B * cap * 16) : 0;
+    const size_t o_uk = take((size_t)B * upi * yh::kUnitSlots * 8);
+    const size_t o_ub = take((size_t)B * upi * yh::kUnitSlots * 16);
+    w.cand_box = with_boxes ? reinterpret_cast<float *>(p + o_cbox) : nullptr;
+    w.ukeys = reinterpret_cast<unsigned long long *>(p + o_uk);
+    w.uboxes = reinterpret_cast<float *>(p + o_ub);
     const size_t o_img = take((size_t)B * 4);
     const size_t o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
     const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
@@ -140,17 +148,58 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
 
-uint32_t plan_stream(yh::StreamParams &p, int B)
+constexpr uint64_t kStreamTargetUnits = 8192;   // wave-private variant: work units (one per wavefront)
+
+long env_knob(const char *name, long fallback)
 {
+    const char *e = std::getenv(name);
+    if (!e) return fallback;
+    const long v = std::atol(e);
+    return v > 0 ? v : fallback;
+}
+
+uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode)
+{
+    // The detection pass runs wave-private tiles of 4 or 8 KiB when a row fits one.
+    p.wave_ni = 0;
+    if (mode == yh::kModeDetect) {
+        const long ni = env_knob("YH_STREAM_NI", 8);             // tuning knob: 4, 8, anything else = workgroup tiles
+        if ((ni == 4 || ni == 8) && (256 * ni - 3) / p.K >= 1) p.wave_ni = (int32_t)ni;
+        else if (ni == 4 && (256 * 8 - 3) / p.K >= 1) p.wave_ni = 8;
+    }
+    if (p.wave_ni) {
+        const long nb = env_knob("YH_STREAM_NBUF", 3);
+        p.wave_nbuf = (nb >= 2 && nb <= (p.wave_ni == 4 ? 4 : 3)) ? (int32_t)nb : 3;
+        p.tile_rows = (256 * p.wave_ni - 3) / p.K;
+        uint64_t total_tiles = 0;
+        for (int s = 0; s < p.S; ++s)
+            total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
+        const uint64_t want = (uint64_t)env_knob("YH_STREAM_UNITS", (long)kStreamTargetUnits);
+        uint64_t tpc = (total_tiles + want / 2) / want;          // tiles per wavefront, nearest
+        if (tpc < 1) tpc = 1;
+        // an image's units are indexed by the candidates -> detections stage: bounded
+        const uint64_t tiles_one_img = total_tiles / (uint64_t)B;
+        const uint64_t tpc_min = (tiles_one_img + (yh::kMaxUnitsPerImage - p.S) - 1) / (yh::kMaxUnitsPerImage - p.S);
+        if (tpc < tpc_min) tpc = tpc_min;
+        uint32_t units = 0, upi = 0;
+        for (int s = 0; s < p.S; ++s) {
+            const uint64_t tiles_img = ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows;
+            const uint64_t chunks = (tiles_img + tpc - 1) / tpc;
+            p.sc[s].tiles_per_chunk = (uint32_t)((tiles_img + chunks - 1) / chunks);   // even split
+            p.sc[s].chunks_per_img = (uint32_t)chunks;
+            p.sc[s].blk_begin = units;
+            p.sc[s].unit_base = upi;
+            units += (uint32_t)chunks * (uint32_t)B;
+            upi += (uint32_t)chunks;
+        }
+        p.upi = (int32_t)upi;
+        return units;                                            // one wavefront per workgroup
+    }
     p.tile_rows = (yh::kTileFloats - 3) / p.K;
     uint64_t total_tiles = 0;
     for (int s = 0; s < p.S; ++s)
         total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
-    uint64_t want = kStreamTargetBlocks;
-    if (const char *e = std::getenv("YH_STREAM_BLOCKS")) {      // tuning knob
-        const long v = std::atol(e);
-        if (v > 0) want = (uint64_t)v;
-    }
+    const uint64_t want = (uint64_t)env_knob("YH_STREAM_BLOCKS", (long)kStreamTargetBlocks);   // tuning knob
     uint64_t tpc = (total_tiles + want / 2) / want;              // tiles per workgroup, nearest
     if (tpc < 1) tpc = 1;
     if (tpc > 64) tpc = 64;
@@ -175,7 +224,7 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
     uint32_t row_base = 0;
     for (int s = 0; s < p.S; ++s) {
         yh::StreamScale &sc = p.sc[s];
-        sc.src = heads[s];
+        sc.src = heads ? heads[s] : nullptr;
         sc.rows_img = (uint32_t)cfg->grid_h[s] * cfg->grid_w[s] * cfg->num_priors;
         sc.span = sc.rows_img * (uint32_t)p.K;
         sc.grid_w = (uint32_t)cfg->grid_w[s];
@@ -245,7 +294,7 @@ int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batc
     fill_stream_from_config(p, cfg, heads, batch);
     p.boxes = boxes;
     p.conf = conf;
-    const uint32_t blocks = plan_stream(p, batch);
+    const uint32_t blocks = plan_stream(p, batch, yh::kModeFull);
     const hipError_t e = yh::launch_stream(p, yh::kModeFull, blocks, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "decode launch");
     return YH_OK;
@@ -259,8 +308,11 @@ int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t 
     if (rc != YH_OK) return rc;
     if (batch < 0 || max_candidates < 1 || nms_max_boxes < 1 || nms_max_boxes > YH_MAX_NMS_BOXES)
         return fail(YH_ERR_INVALID_ARG, "bad batch / max_candidates / nms_max_boxes");
+    yh::StreamParams p;
+    fill_stream_from_config(p, cfg, nullptr, batch);
+    if (batch > 0) plan_stream(p, batch, yh::kModeDetect);
     *bytes = carve_detect(nullptr, batch, boxes_per_image(cfg), cfg->num_classes, max_candidates,
-                          nms_max_boxes, true).bytes;
+                          nms_max_boxes, true, p.upi).bytes;
     return YH_OK;
 }
 
@@ -271,7 +323,7 @@ int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_img, int32_t num_cla
     if (batch < 0 || boxes_per_img < 1 || num_classes < 1 || max_candidates < 1 || nms_max_boxes < 1 ||
         nms_max_boxes > YH_MAX_NMS_BOXES)
         return fail(YH_ERR_INVALID_ARG, "bad size argument");
-    *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false).bytes;
+    *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, 0).bytes;
     return YH_OK;
 }
 
@@ -293,10 +345,9 @@ static yh::NmsParams make_nms_params(const DetectWs &w, int32_t B, int32_t C, in
 }
 
 // Streaming pass, then the candidates -> detections stage.
-static int run_pipeline(yh::StreamParams &p, yh::StreamMode mode, const yh::NmsParams &q,
-                        int32_t batch, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end)
+static int run_pipeline(const yh::StreamParams &p, yh::StreamMode mode, uint32_t blocks, const yh::NmsParams &q,
+                        hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
-    const uint32_t blocks = plan_stream(p, batch);
     hipError_t e;
     if (ev_begin && (e = hipEventRecord(ev_begin, st)) != hipSuccess) return hip_fail(e, "event record");
     e = yh::launch_stream(p, mode, blocks, st);
@@ -324,24 +375,35 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (reinterpret_cast<uintptr_t>(out_boxes) & 15u))
         return fail(YH_ERR_ALIGN, "workspace must be 256-byte and out_boxes 16-byte aligned");
     const int64_t N = boxes_per_image(cfg);
-    const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true);
+    yh::StreamParams p;
+    fill_stream_from_config(p, cfg, heads, batch);
+    const uint32_t blocks = plan_stream(p, batch, yh::kModeDetect);
+    const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true, p.upi);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    yh::StreamParams p;
-    fill_stream_from_config(p, cfg, heads, batch);
     p.thr = score_threshold;
     p.prefilter = prefilter_logit(score_threshold);
     p.cand_cap = max_candidates;
     p.cand = w.cand;
     p.img_count = w.img_count;
     p.boxes = w.boxes;
-    const yh::NmsParams q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
-                                            nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
-                                            out_class, out_index, out_class_candidates, status);
-    return run_pipeline(p, yh::kModeDetect, q, batch, st, ev_begin, ev_end);
+    p.cand_box = w.cand_box;
+    p.ukeys = w.ukeys;
+    p.uboxes = w.uboxes;
+    yh::NmsParams q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
+                                      nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
+                                      out_class, out_index, out_class_candidates, status);
+    if (p.wave_ni) {                          // candidates arrive with slot-indexed boxes
+        q.upi = p.upi;
+        q.ukeys = w.ukeys;
+        q.uboxes = w.uboxes;
+        q.cand_box = w.cand_box;
+        q.boxes_fill = w.boxes;
+    }
+    return run_pipeline(p, yh::kModeDetect, blocks, q, st, ev_begin, ev_end);
 }
 
 int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
@@ -391,7 +453,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     if ((reinterpret_cast<uintptr_t>(boxes) & 15u) || (reinterpret_cast<uintptr_t>(conf) & 15u) ||
         (reinterpret_cast<uintptr_t>(out_boxes) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(YH_ERR_ALIGN, "boxes / conf / out_boxes must be 16-byte and workspace 256-byte aligned");
-    const DetectWs w = carve_detect(workspace, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false);
+    const DetectWs w = carve_detect(workspace, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, 0);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
@@ -414,7 +476,8 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     const yh::NmsParams q = make_nms_params(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold,
                                             nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
                                             out_class, out_index, out_class_candidates, status);
-    return run_pipeline(p, yh::kModeConf, q, batch, st, nullptr, nullptr);
+    const uint32_t blocks = plan_stream(p, batch, yh::kModeConf);
+    return run_pipeline(p, yh::kModeConf, blocks, q, st, nullptr, nullptr);
 }
 
 static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batch, int32_t pad)

@@ -44,13 +44,23 @@ __device__ __forceinline__ float sigmoid_ce(float x, float z)
 }
 
 // ---- streaming pass (decode / threshold / compaction) --------------------
+// Candidates leave the streaming pass in two places.  The wave-private variant
+// gives every work unit (one wavefront's run of rows of one image) kUnitSlots
+// private slots of (key, box), written with plain stores and no atomic (unused
+// slots get kEmptySlot); whatever exceeds them, and everything the workgroup-tile variant
+// finds, goes to the image's list, whose range is reserved with a global atomic.
+constexpr int kUnitSlots = 16;
+constexpr int kMaxUnitsPerImage = 1024;
+constexpr unsigned long long kEmptySlot = ~0ull;   // no candidate: its score field would be a NaN
+
 struct StreamScale {
     const float *src;       // head [B][rows_img][K] or conf [B][rows_img][K]
     uint32_t rows_img;      // rows of one image at this scale
     uint32_t span;          // rows_img * K floats
     uint32_t grid_w;
     uint32_t row_base;      // first box row of this scale inside an image
-    uint32_t blk_begin;     // first workgroup of this scale inside an image's run of workgroups
+    uint32_t blk_begin;     // first workgroup of this scale in the launch
+    uint32_t unit_base;     // wave-private variant: first work unit of this scale inside an image
     uint32_t chunks_per_img;
     uint32_t tiles_per_chunk;   // tiles one workgroup walks
     float mult;
@@ -60,13 +70,19 @@ struct StreamScale {
 struct StreamParams {
     int32_t S, B, C, P, K, N;
     uint32_t magic_k;       // floor(2^32 / K) + 1
-    int32_t tile_rows;      // rows per LDS tile: floor((kTileFloats - 3) / K)
+    int32_t tile_rows;      // rows per LDS tile: floor((tile floats - 3) / K)
+    int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
+    int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
+    int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     float thr;              // score threshold
     float prefilter;        // logits below this cannot reach thr
     int32_t cand_cap;
     unsigned long long *cand;   // [B][cand_cap]
+    float *cand_box;            // [B][cand_cap][4] boxes of the list entries (wave-private variant)
     int32_t *img_count;         // [B], zero on entry; the kernel that consumes it zeroes it again
-    float *boxes;               // [B][N][4]
+    unsigned long long *ukeys;  // [B][upi][kUnitSlots]
+    float *uboxes;              // [B][upi][kUnitSlots][4]
+    float *boxes;               // [B][N][4] (workgroup-tile variant and full decode)
     float *conf;                // [B][N][C] (full decode only, may be null)
     StreamScale sc[YH_MAX_SCALES];
 };
@@ -83,7 +99,11 @@ struct NmsParams {
     int32_t cand_cap;
     int32_t max_boxes;
     float iou_thr;
+    int32_t upi;                       // work units per image with private slots; 0: the list only
+    const unsigned long long *ukeys;   // [B][upi][kUnitSlots]
+    const float *uboxes;               // [B][upi][kUnitSlots][4]
     const unsigned long long *cand;    // [B][cand_cap] unordered
+    const float *cand_box;             // [B][cand_cap][4], or null: a candidate's box is boxes[row]
     unsigned long long *seg_keys;      // [B][cand_cap] binned by class, then sorted
     int32_t *img_count;                // [B]; zeroed again once consumed
     int32_t *seg_off;                  // [B][C]
@@ -91,7 +111,9 @@ struct NmsParams {
     int32_t *kept_cnt;                 // [B][C]
     int32_t *kept_row;                 // [B][C][max_boxes]
     float *kept_score;                 // [B][C][max_boxes]
-    const float *boxes;                // [B][N][4]
+    const float *boxes;                // [B][N][4] indexed by box row
+    float *boxes_fill;                 // same array when the multi-launch path has to fill it from the
+                                       // slot-indexed boxes, else null
     int32_t *out_count;                // [B]
     float *out_scores;                 // [B][C*max_boxes]
     float *out_boxes;                  // [B][C*max_boxes][4]

@@ -26,53 +26,77 @@ __global__ __launch_bounds__(kPostThreads) void k_post(const NmsParams p)
     extern __shared__ __align__(16) float s_kbox_all[];
     __shared__ unsigned long long s_keys[kPostCap];
     __shared__ unsigned long long s_sorted[kPostRankMax];
-    __shared__ float4 s_box[kPostCap];
+    __shared__ float4 s_ubox[kPostCap];
+    __shared__ float4 s_box[kPostRankMax];
     __shared__ uint16_t s_kpos[kPostKeptMax];
     __shared__ int s_off[kPostMaxClasses];
     __shared__ int s_seg[kPostMaxClasses];
     __shared__ int s_cnt[kPostMaxClasses];
     __shared__ int s_kept[kPostMaxClasses];
     __shared__ int s_wave[kPostThreads / 64];
+    __shared__ int s_total;
     PostLds l;
-    l.keys = s_keys; l.sorted = s_sorted; l.box = s_box; l.kpos = s_kpos;
-    l.off = s_off; l.seg = s_seg; l.cnt = s_cnt; l.kept = s_kept; l.wave_sums = s_wave; l.kbox_all = s_kbox_all;
+    l.keys = s_keys; l.sorted = s_sorted; l.ubox = s_ubox; l.box = s_box; l.kpos = s_kpos;
+    l.off = s_off; l.seg = s_seg; l.cnt = s_cnt; l.kept = s_kept; l.wave_sums = s_wave; l.total = &s_total; l.kbox_all = s_kbox_all;
     post_image<kPostThreads, kPostMaxClasses / kPostThreads>(p, blockIdx.x, l, kPostRankMax);
 }
 
 // ------------------------------------------------ general path: bin, sort+nms, finalize
 // One workgroup per image: class histogram, exclusive scan, scatter into class
 // segments.  The order inside a segment is arbitrary; the sort that follows
-// makes the result independent of it because keys are unique.
+// makes the result independent of it because keys are unique.  When more
+// candidates were found than the capacity holds, the segments are cut off at the
+// capacity in class order and the image is flagged.
 __global__ __launch_bounds__(kBinThreads) void k_bin(const NmsParams p)
 {
-    __shared__ int s_hist[YH_MAX_CLASSES];
+    __shared__ int s_cur[YH_MAX_CLASSES];    // histogram, then each segment's write cursor
+    __shared__ int s_end[YH_MAX_CLASSES];    // count, then each segment's end
     __shared__ int s_wave[kBinThreads / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, C = p.C;
+    const int b = blockIdx.x, tid = threadIdx.x, C = p.C, cap = p.cand_cap;
     const int raw = p.img_count[b];
-    const int M = raw < p.cand_cap ? raw : p.cand_cap;
-    for (int c = tid; c < C; c += kBinThreads) s_hist[c] = 0;
+    for (int c = tid; c < C; c += kBinThreads) s_cur[c] = 0;
     __syncthreads();
-    if (tid == 0) {
-        p.img_count[b] = 0;                                   // leaves the counter clean for the next call
-        p.status[b] = raw > p.cand_cap ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
-    }
-    const unsigned long long *keys = p.cand + (long long)b * p.cand_cap;
-    for (int i = tid; i < M; i += kBinThreads) atomicAdd(&s_hist[key_class(keys[i])], 1);
+    cand_for_each<kBinThreads, false>(p, b, raw, [&](unsigned long long k, float4) {
+        atomicAdd(&s_cur[key_class(k)], 1);
+    });
+    __syncthreads();
+    for (int c = tid; c < C; c += kBinThreads) s_end[c] = s_cur[c];
+    __syncthreads();
+    block_exclusive_scan<kBinThreads, YH_MAX_CLASSES / kBinThreads>(s_cur, C, s_wave);
+    const int found = s_cur[C - 1] + s_end[C - 1];
     __syncthreads();
     for (int c = tid; c < C; c += kBinThreads) {
-        const int n = s_hist[c];
+        const int o = s_cur[c] < cap ? s_cur[c] : cap;
+        const int n = s_end[c] < cap - o ? s_end[c] : cap - o;
+        p.seg_off[b * C + c] = o;
         p.seg_cnt[b * C + c] = n;
         if (p.out_class_candidates) p.out_class_candidates[b * C + c] = n;
+        s_cur[c] = o;
+        s_end[c] = o + n;
+    }
+    if (tid == 0) {
+        p.img_count[b] = 0;                                   // leaves the counter clean for the next call
+        p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
     }
     __syncthreads();
-    block_exclusive_scan<kBinThreads, YH_MAX_CLASSES / kBinThreads>(s_hist, C, s_wave);
-    for (int c = tid; c < C; c += kBinThreads) p.seg_off[b * C + c] = s_hist[c];
-    __syncthreads();
-    unsigned long long *out = p.seg_keys + (long long)b * p.cand_cap;
-    for (int i = tid; i < M; i += kBinThreads) {
-        const unsigned long long k = keys[i];
-        const int pos = atomicAdd(&s_hist[key_class(k)], 1);
-        out[pos] = k;
+    unsigned long long *out = p.seg_keys + (long long)b * cap;
+    float4 *fill = p.boxes_fill ? reinterpret_cast<float4 *>(p.boxes_fill) + (long long)b * p.N : nullptr;
+    if (fill) {
+        // the later launches find a candidate's box under its row
+        cand_for_each<kBinThreads, true>(p, b, raw, [&](unsigned long long k, float4 box) {
+            const int c = key_class(k);
+            const int pos = atomicAdd(&s_cur[c], 1);
+            if (pos < s_end[c]) {
+                out[pos] = k;
+                fill[key_row(k)] = box;
+            }
+        });
+    } else {
+        cand_for_each<kBinThreads, false>(p, b, raw, [&](unsigned long long k, float4) {
+            const int c = key_class(k);
+            const int pos = atomicAdd(&s_cur[c], 1);
+            if (pos < s_end[c]) out[pos] = k;
+        });
     }
 }
 

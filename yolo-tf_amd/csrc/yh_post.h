@@ -1,6 +1,5 @@
-// Device-side building blocks of the candidates -> detections stage, shared by
-// the stand-alone kernels (yh_nms.hip) and by the streaming kernel, whose last
-// workgroup of an image runs the stage in place (yh_stream.hip).
+// Device-side building blocks of the candidates -> detections stage (kernels:
+// yh_nms.hip).
 #pragma once
 #include "yh_internal.h"
 
@@ -72,6 +71,68 @@ __device__ inline void bitonic_sort(unsigned long long *a, int cnt, int n2)
             }
             __syncthreads();
         }
+    }
+}
+
+// Same network on (key, value) pairs: the values follow their keys.
+template <int THREADS>
+__device__ inline void bitonic_sort_kv(unsigned long long *a, float4 *v, int cnt, int n2)
+{
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= n2; k <<= 1) {
+        const int half = k >> 1;
+        for (int t = tid; t < (n2 >> 1); t += THREADS) {
+            const int blk = t / half, off = t - blk * half;
+            const int i = blk * k + off, l = blk * k + (k - 1 - off);
+            if (l < cnt) {
+                const unsigned long long x = a[i], y = a[l];
+                if (x > y) { a[i] = y; a[l] = x; const float4 tv = v[i]; v[i] = v[l]; v[l] = tv; }
+            }
+        }
+        __syncthreads();
+        for (int j = half >> 1; j >= 1; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += THREADS) {
+                const int i = (t / j) * 2 * j + (t % j), l = i + j;
+                if (l < cnt) {
+                    const unsigned long long x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; const float4 tv = v[i]; v[i] = v[l]; v[l] = tv; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- the candidates of one image ------------------------------------------
+// They sit in the work units' private slots (ukeys / uboxes; an unused slot holds
+// kEmptySlot) and in the image's list (img_count / cand / cand_box, or boxes[row]
+// when cand_box is null).  f(key, box) is called for each, in no particular
+// order, by whichever thread read it; box is read only when WANT_BOX.  Slot keys
+// and boxes are requested together, before a key is looked at, so that one
+// memory round trip brings in everything.  list_raw: img_count[b].
+template <int THREADS, bool WANT_BOX, typename F>
+__device__ inline void cand_for_each(const NmsParams &p, int b, int list_raw, F f)
+{
+    const int tid = threadIdx.x, nslots = p.upi * kUnitSlots;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long *uk = p.ukeys + (long long)b * nslots;
+    const float4 *ub = reinterpret_cast<const float4 *>(p.uboxes) + (long long)b * nslots;
+    for (int e = tid; e < nslots; e += THREADS) {
+        const unsigned long long k = uk[e];
+        float4 box = zero;
+        if (WANT_BOX) {
+            box = ub[e];
+            asm volatile("" ::"v"(box.x));                    // keeps the load next to the key's, ahead of the test
+        }
+        if (k != kEmptySlot) f(k, box);
+    }
+    const int nl = list_raw < p.cand_cap ? list_raw : p.cand_cap;
+    const unsigned long long *cand = p.cand + (long long)b * p.cand_cap;
+    const float4 *cb = p.cand_box ? reinterpret_cast<const float4 *>(p.cand_box) + (long long)b * p.cand_cap : nullptr;
+    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+    for (int i = tid; i < nl; i += THREADS) {
+        const unsigned long long k = cand[i];
+        f(k, WANT_BOX ? (cb ? cb[i] : boxes4[key_row(k)]) : zero);
     }
 }
 
@@ -174,59 +235,79 @@ __device__ inline int wave_nms(const unsigned long long *keys, int cnt, const fl
 
 // LDS working set of post_image, carved by the caller.
 struct PostLds {
-    unsigned long long *keys;     // [cap]
+    unsigned long long *keys;     // [cap] in arrival order (sorted in place beyond rank_max)
     unsigned long long *sorted;   // [rank_max]
-    float4 *box;                  // [cap]
+    float4 *ubox;                 // [cap] boxes of keys[]
+    float4 *box;                  // [rank_max] boxes of sorted[]
     uint16_t *kpos;               // [C * max_boxes]
     int *off, *seg, *cnt, *kept;  // [C] each
     int *wave_sums;               // [THREADS / 64]
+    int *total;                   // [1]
     float *kbox_all;              // [THREADS / 64][max_boxes][5]
 };
 
+constexpr int kNmsGroup = 16;     // lanes that share one short class segment (== kLaneNmsMax)
+
 // Candidates of image b -> its detections, by one workgroup of THREADS threads,
-// everything in LDS between the candidate list and the outputs: keys sorted by
-// the full key (class ascending, score descending, row ascending; rank sort up
-// to rank_max keys, bitonic beyond), the candidates' boxes gathered once with
-// all loads in flight, the wavefronts take the class segments in turn, the
-// selections are concatenated (YOLOv3.py:362-367).  C <= THREADS * SCAN_ITEMS.
-// Zeroes img_count[b] for the next call.
+// everything in LDS between the candidate slots and the outputs: keys and boxes
+// loaded together, keys sorted by the full key (class ascending, score
+// descending, row ascending; rank sort up to rank_max keys, bitonic beyond) with
+// the boxes following them, the class segments walked by groups of 16 lanes
+// (short ones) or wavefronts, the selections concatenated (YOLOv3.py:362-367).
+// C <= THREADS * SCAN_ITEMS.  Zeroes img_count[b] for the next call.
 template <int THREADS, int SCAN_ITEMS>
 __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, int rank_max)
 {
-    const int tid = threadIdx.x, wave = tid >> 6, C = p.C, mb = p.max_boxes;
+    static_assert(kNmsGroup == kLaneNmsMax, "one lane per candidate of a short segment");
+    const int tid = threadIdx.x, wave = tid >> 6, C = p.C, mb = p.max_boxes, cap = p.cand_cap;
     const int raw = p.img_count[b];
-    const int M = raw < p.cand_cap ? raw : p.cand_cap;
     for (int c = tid; c < C; c += THREADS) { l.cnt[c] = 0; l.kept[c] = 0; }
+    if (tid == 0) *l.total = 0;
     __syncthreads();
+    cand_for_each<THREADS, true>(p, b, raw, [&](unsigned long long k, float4 box) {
+        const int pos = atomicAdd(l.total, 1);
+        if (pos < cap) {
+            l.keys[pos] = k;
+            l.ubox[pos] = box;
+            atomicAdd(&l.cnt[key_class(k)], 1);
+        }
+    });
+    __syncthreads();
+    const int found = *l.total;
+    const int M = found < cap ? found : cap;
     if (tid == 0) {
         p.img_count[b] = 0;                                   // leaves the counter clean for the next call
-        p.status[b] = raw > p.cand_cap ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
+        // the list keeps at most `cap` of the `raw` entries its producers counted
+        p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
     }
-    const unsigned long long *cand = p.cand + (long long)b * p.cand_cap;
-    for (int i = tid; i < M; i += THREADS) {
-        const unsigned long long k = cand[i];
-        l.keys[i] = k;
-        atomicAdd(&l.cnt[key_class(k)], 1);
-    }
-    __syncthreads();
     const unsigned long long *sorted;
+    const float4 *sbox;
     if (M <= rank_max) {
-        for (int i = tid; i < M; i += THREADS) {
-            const unsigned long long key = l.keys[i];
+        // rank sort, four lanes per key: each counts the smaller keys in a quarter of the list
+        const int q = tid & 3;
+        const int j0 = (M * q) >> 2, j1 = (M * (q + 1)) >> 2;
+        for (int i0 = 0; i0 < M; i0 += THREADS / 4) {
+            const int i = i0 + (tid >> 2);
+            const unsigned long long key = i < M ? l.keys[i] : 0ull;
             int rank = 0;
-            for (int j = 0; j < M; ++j) rank += l.keys[j] < key ? 1 : 0;   // broadcast reads; keys are unique
-            l.sorted[rank] = key;
+            for (int j = j0; j < j1; ++j) rank += l.keys[j] < key ? 1 : 0;   // keys are unique
+            rank += __shfl_xor(rank, 1, 64);
+            rank += __shfl_xor(rank, 2, 64);
+            if (i < M && q == 0) {
+                l.sorted[rank] = key;
+                l.box[rank] = l.ubox[i];
+            }
         }
         __syncthreads();
         sorted = l.sorted;
+        sbox = l.box;
     } else {
         int n2 = 64;
         while (n2 < M) n2 <<= 1;
-        bitonic_sort<THREADS>(l.keys, M, n2);
+        bitonic_sort_kv<THREADS>(l.keys, l.ubox, M, n2);
         sorted = l.keys;
+        sbox = l.ubox;
     }
-    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
-    for (int i = tid; i < M; i += THREADS) l.box[i] = boxes4[key_row(sorted[i])];
     for (int c = tid; c < C; c += THREADS) {
         const int n = l.cnt[c];
         l.off[c] = n;
@@ -237,30 +318,39 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     for (int c = tid; c < C; c += THREADS) l.seg[c] = l.off[c];
     __syncthreads();
 
-    // Short segments (the usual case at detection thresholds): one LANE per class runs the
-    // same greedy walk serially, all classes at once; the selections are read back from kpos.
-    for (int c = tid; c < C; c += THREADS) {
-        const int cnt = l.cnt[c];
-        if (cnt == 0 || cnt > kLaneNmsMax) continue;
-        const int off = l.seg[c];
-        uint16_t *kp = l.kpos + c * mb;
-        int kept = 0;
-        for (int i = 0; i < cnt && kept < mb; ++i) {
-            const float4 bi = l.box[off + i];
+    // Short segments (the usual case at detection thresholds): a group of 16 lanes per
+    // class, one lane per candidate.  Lane i collects the bits "the earlier candidate j
+    // would suppress me"; the greedy walk over those bits is then a few integer steps,
+    // done redundantly by every lane of the group.
+    {
+        const int gl = tid & (kNmsGroup - 1);
+        for (int c = tid / kNmsGroup; c < C; c += THREADS / kNmsGroup) {
+            const int cnt = l.cnt[c];
+            if (cnt == 0 || cnt > kLaneNmsMax) continue;
+            const int off = l.seg[c];
+            const bool valid = gl < cnt;
+            const float4 bi = sbox[off + (valid ? gl : 0)];
             const float ymin = fminf(bi.x, bi.z), xmin = fminf(bi.y, bi.w);
             const float ymax = fmaxf(bi.x, bi.z), xmax = fmaxf(bi.y, bi.w);
             const float area = (ymax - ymin) * (xmax - xmin);
-            bool keep = true;
-            for (int j = kept - 1; j >= 0 && keep; --j) {
-                const float4 bj = l.box[kp[j]];
+            uint32_t mymask = 0;
+            for (int j = 0; j + 1 < cnt; ++j) {
+                const float4 bj = sbox[off + j];
                 const float jy0 = fminf(bj.x, bj.z), jx0 = fminf(bj.y, bj.w);
                 const float jy1 = fmaxf(bj.x, bj.z), jx1 = fmaxf(bj.y, bj.w);
-                if (suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, (jy1 - jy0) * (jx1 - jx0), p.iou_thr))
-                    keep = false;
+                if (valid && gl > j &&
+                    suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, (jy1 - jy0) * (jx1 - jx0), p.iou_thr))
+                    mymask |= 1u << j;
             }
-            if (keep) kp[kept++] = (uint16_t)(off + i);
+            uint32_t keepmask = 0;
+            int kept = 0;
+            for (int j = 0; j < cnt && kept < mb; ++j) {
+                const uint32_t mj = (uint32_t)__shfl((int)mymask, j, kNmsGroup);
+                if ((mj & keepmask) == 0u) { keepmask |= 1u << j; ++kept; }
+            }
+            if ((keepmask >> gl) & 1u) l.kpos[c * mb + __popc(keepmask & ((1u << gl) - 1u))] = (uint16_t)(off + gl);
+            if (gl == 0) l.kept[c] = kept;
         }
-        l.kept[c] = kept;
     }
     // longer segments: one wavefront per class
     float (*kbox)[5] = reinterpret_cast<float (*)[5]>(l.kbox_all + (size_t)wave * mb * 5);
@@ -268,7 +358,7 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
         const int cnt = l.cnt[c];
         if (cnt <= kLaneNmsMax) continue;
         const int off = l.seg[c];
-        const int kept = wave_nms<true>(sorted + off, cnt, nullptr, l.box + off, kbox, p.iou_thr, mb,
+        const int kept = wave_nms<true>(sorted + off, cnt, nullptr, sbox + off, kbox, p.iou_thr, mb,
                                         nullptr, nullptr, l.kpos + c * mb, off);
         if ((tid & 63) == 0) l.kept[c] = kept;
     }
@@ -276,15 +366,15 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     for (int c = tid; c < C; c += THREADS) l.off[c] = l.kept[c];
     __syncthreads();
     block_exclusive_scan<THREADS, SCAN_ITEMS>(l.off, C, l.wave_sums);
-    const int cap = C * mb;
-    for (int e = tid; e < cap; e += THREADS) {
+    const int ocap = C * mb;
+    for (int e = tid; e < ocap; e += THREADS) {
         const int c = e / mb, j = e - c * mb;
         if (j < l.kept[c]) {
             const int pos = l.kpos[e];
             const unsigned long long key = sorted[pos];
-            const long long dst = (long long)b * cap + l.off[c] + j;
+            const long long dst = (long long)b * ocap + l.off[c] + j;
             p.out_scores[dst] = key_score(key);
-            reinterpret_cast<float4 *>(p.out_boxes)[dst] = l.box[pos];
+            reinterpret_cast<float4 *>(p.out_boxes)[dst] = sbox[pos];
             p.out_class[dst] = c;
             p.out_index[dst] = key_row(key);
         }

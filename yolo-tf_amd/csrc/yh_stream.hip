@@ -189,6 +189,242 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     flush_candidates(st, p, b);
 }
 
+// ------------------------------------------------------------ wave-private variant
+// Same pass with no workgroup-level synchronisation at all: a workgroup is one
+// wavefront that owns a ring of NBUF LDS tile buffers (NI KiB each, whole rows)
+// and a run of tiles of one image.  The LDS-DMA loads of the next NBUF-1 tiles
+// stay in flight while the wavefront looks at the current one; it waits with a
+// counted s_waitcnt instead of a barrier.  Vector-memory operations of a
+// wavefront complete in issue order, and every tile is exactly NI loads, so
+// "at most NI * (tiles issued later) operations outstanding" proves that the
+// current tile has landed, whatever stores were issued in between.
+//
+// Every LDS read of a tile goes through inline assembly: before an LDS read it
+// can see, the compiler waits for all outstanding LDS-DMA loads, the later
+// tiles included, which would serialise the ring.
+//
+// Per tile: wait, one ds_read of the rows' objectness logits, one ballot, issue
+// the tile NBUF ahead.  Rows that pass the objectness prefilter (a few percent)
+// spread their class logits over the 64 lanes; candidates are compacted by
+// ballot into a wave-private stage and appended with one global atomic per
+// flush (normally one per work unit).
+constexpr int kWaveStage = 128;   // staged keys per wave; flushed at >= 64, one step adds <= 64
+
+typedef __attribute__((address_space(3))) float lds_float_t;
+
+__device__ __forceinline__ float lds_peek(uint32_t addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// five consecutive floats (t_y, t_x, t_h, t_w, objectness)
+__device__ __forceinline__ void lds_peek5(uint32_t addr, float &a, float &b, float &c, float &d, float &e)
+{
+    asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:4\n\tds_read_b32 %2, %5 offset:8\n\t"
+                 "ds_read_b32 %3, %5 offset:12\n\tds_read_b32 %4, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e)
+                 : "v"(addr)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct WaveCtx {
+    const StreamScale *sc;
+    const float4 *src4;
+    long long s0, total, q_last;
+    uint32_t row_end;
+    int K, R;
+};
+
+// Issues the loads of the tile that starts at row `row_t` into `tb`.  Returns true
+// when the tile is covered by exactly NI LDS-DMA instructions and nothing else.
+template <int NI>
+__device__ __forceinline__ bool wave_issue_tile(const WaveCtx &w, uint32_t row_t, float *tb, int lane)
+{
+    const int rows_t = (int)((w.row_end - row_t) < (uint32_t)w.R ? (w.row_end - row_t) : (uint32_t)w.R);
+    const long long f0 = w.s0 + (long long)row_t * w.K;
+    const long long q0 = f0 >> 2;
+    const int sh = (int)(f0 & 3);
+    const int wslots = (sh + rows_t * w.K + 3) >> 2;          // <= NI * 64
+    const long long nd = w.q_last - q0 + 1;
+    const int ndma = nd < wslots ? (int)(nd < 0 ? 0 : nd) : wslots;
+    if (ndma > 0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int slot = j * 64 + lane;
+            slot = slot < ndma ? slot : ndma - 1;             // lanes past the end re-read the last slot
+            __builtin_amdgcn_global_load_lds((gptr_t *)(w.src4 + q0 + slot), (lptr_t *)(tb + j * 256), 16, 0, 0);
+        }
+    }
+    if (ndma < wslots) {                                      // the tensor's last, partial slot: 1..3 floats
+        const int left = (int)(w.total - (q0 + ndma) * 4);
+        if (lane < left) tb[ndma * 4 + lane] = w.sc->src[(q0 + ndma) * 4 + lane];
+    }
+    return ndma == wslots;
+}
+
+// Writes the staged candidates out.  `emitted` counts the unit's candidates written by
+// earlier calls: the first kUnitSlots of a unit go to its private slots, the rest to the
+// image's list (one global atomic reserves the range).
+struct WaveOut {
+    unsigned long long *ukeys;   // this unit's slots
+    float4 *uboxes;
+    unsigned long long *cand;    // this image's list
+    float4 *cand_box;
+    int32_t *img_count;          // this image's list counter
+    int cand_cap;
+};
+
+__device__ __forceinline__ void wave_flush(const WaveOut &o, const unsigned long long *keys, const float4 *boxes,
+                                           int &count, int &emitted, int lane)
+{
+    int n_unit = kUnitSlots - emitted;
+    n_unit = n_unit < 0 ? 0 : (n_unit < count ? n_unit : count);
+    const int n_list = count - n_unit;
+    int base = 0;
+    if (n_list > 0) {
+        if (lane == 0) base = atomicAdd(o.img_count, n_list);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < count; i += 64) {
+        if (i < n_unit) {
+            o.ukeys[emitted + i] = keys[i];
+            o.uboxes[emitted + i] = boxes[i];
+        } else {
+            const int g = base + (i - n_unit);
+            if (g < o.cand_cap) {
+                o.cand[g] = keys[i];
+                o.cand_box[g] = boxes[i];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    emitted += count;
+    count = 0;
+}
+
+template <int NI, int NBUF>
+__global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p)
+{
+    constexpr int kBuf = NI * 256;                            // floats per tile buffer
+    __shared__ __attribute__((aligned(16))) float s_tile[NBUF][kBuf];
+    __shared__ __attribute__((aligned(16))) float4 s_box[kWaveStage];
+    __shared__ unsigned long long s_keys[kWaveStage];
+    const int lane = threadIdx.x;
+    const uint32_t unit = blockIdx.x;
+
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && unit >= p.sc[i].blk_begin) s = i;
+    const StreamScale &sc = p.sc[s];
+    const uint32_t r = unit - sc.blk_begin;
+    const int b = (int)(r / sc.chunks_per_img);
+    const uint32_t chunk = r - (uint32_t)b * sc.chunks_per_img;
+    const long long u = (long long)b * p.upi + sc.unit_base + chunk;   // this unit's index in the batch
+
+    const int K = p.K, C = p.C, R = p.tile_rows;
+    WaveCtx w;
+    w.sc = &sc;
+    w.src4 = reinterpret_cast<const float4 *>(sc.src);
+    w.s0 = (long long)b * sc.span;
+    w.total = (long long)p.B * sc.span;
+    w.q_last = (w.total >> 2) - 1;
+    w.K = K; w.R = R;
+    const uint32_t row_begin = chunk * sc.tiles_per_chunk * (uint32_t)R;
+    uint32_t row_end = row_begin + sc.tiles_per_chunk * (uint32_t)R;
+    if (row_end > sc.rows_img) row_end = sc.rows_img;
+    const int ntiles = row_begin < row_end ? (int)((row_end - row_begin + (uint32_t)R - 1) / (uint32_t)R) : 0;
+    w.row_end = row_end;
+    const float pf = p.prefilter;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    WaveOut o;
+    o.ukeys = p.ukeys + u * kUnitSlots;
+    o.uboxes = reinterpret_cast<float4 *>(p.uboxes) + u * kUnitSlots;
+    o.cand = p.cand + (long long)b * p.cand_cap;
+    o.cand_box = reinterpret_cast<float4 *>(p.cand_box) + (long long)b * p.cand_cap;
+    o.img_count = p.img_count + b;
+    o.cand_cap = p.cand_cap;
+
+    // `irregular`: a tile in flight is not exactly NI loads (the tensor's last
+    // slots), so only a full wait proves anything from here on.
+    bool irregular = false;
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i)
+        if (i < ntiles) irregular |= !wave_issue_tile<NI>(w, row_begin + (uint32_t)i * (uint32_t)R, s_tile[i], lane);
+    int count = 0;                                            // staged candidates, wave-uniform
+    int emitted = 0;                                          // candidates of this unit already written out
+    int buf = 0;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const uint32_t row_t = row_begin + (uint32_t)t * (uint32_t)R;
+        const int rows_t = (int)((row_end - row_t) < (uint32_t)R ? (row_end - row_t) : (uint32_t)R);
+        float *tb = s_tile[buf];
+        const int sh = (int)((w.s0 + (long long)row_t * K) & 3);
+        const int later = ntiles - 1 - t;                     // tiles issued after this one: min(later, NBUF - 1)
+        if (irregular || later == 0) wait_vmcnt<0>();
+        else if (NBUF == 2 || later == 1) wait_vmcnt<NI>();
+        else if (NBUF == 3 || later == 2) wait_vmcnt<2 * NI>();
+        else wait_vmcnt<3 * NI>();
+        const uint32_t row0_off = (uint32_t)(uintptr_t)(lds_float_t *)tb + (uint32_t)sh * 4u;
+        for (int r0 = 0; r0 < rows_t; r0 += 64) {
+            const int rr = r0 + lane;
+            const int rc = rr < rows_t ? rr : rows_t - 1;
+            const float obj_l = lds_peek(row0_off + (uint32_t)(rc * K + C + 4) * 4u);
+            unsigned long long mask = __ballot(rr < rows_t && obj_l >= pf);
+            while (mask) {                                    // wave-uniform: one surviving row per turn
+                const int bit = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int rit = r0 + bit;
+                const uint32_t rp_off = row0_off + (uint32_t)(rit * K) * 4u;
+                float ty, tx, th, tw, obj;
+                lds_peek5(rp_off + (uint32_t)C * 4u, ty, tx, th, tw, obj);
+                const float so = sigmoidf(obj);
+                const uint32_t row = row_t + (uint32_t)rit;
+                const int n = (int)(sc.row_base + row);
+                bool have_box = false;
+                float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c0 = 0; c0 < C; c0 += 64) {
+                    const int c = c0 + lane;
+                    const float x = lds_peek(rp_off + (uint32_t)(c < C ? c : C - 1) * 4u);
+                    bool hit = false;
+                    float cf = 0.0f;
+                    if (c < C && x >= pf) {
+                        cf = sigmoidf(x) * so;
+                        hit = cf >= p.thr;
+                    }
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm == 0) continue;
+                    if (!have_box) {                          // the row's box, once, in every lane
+                        box = decode_box(p.P, sc, ty, tx, th, tw, row);
+                        have_box = true;
+                    }
+                    if (hit) {
+                        const int pos = count + __builtin_popcountll(hm & lanes_below);
+                        s_keys[pos] = make_key(c, cf, n);
+                        s_box[pos] = box;
+                    }
+                    count += __builtin_popcountll(hm);
+                    if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
+                }
+            }
+        }
+        if (t + NBUF < ntiles)
+            irregular |= !wave_issue_tile<NI>(w, row_t + (uint32_t)NBUF * (uint32_t)R, tb, lane);
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+    if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
+    if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
+}
+
 // Full decode (yh_decode): boxes [B][N][4] and, optionally, conf [B][N][C].
 // grid = (ceil(span / 256), B) per scale: one element of the head per lane,
 // coalesced loads and stores; the row's objectness comes from the cache.
@@ -223,7 +459,19 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
     }
     if (blocks == 0) return hipSuccess;
     const dim3 grid(blocks), block(kThreads);
-    if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
+    if (mode == kModeDetect && p.wave_ni) {
+        const dim3 wblock(64);
+        const int key = p.wave_ni * 10 + p.wave_nbuf;
+        switch (key) {
+        case 42: hipLaunchKernelGGL((k_stream_wave<4, 2>), grid, wblock, 0, stm, p); break;
+        case 43: hipLaunchKernelGGL((k_stream_wave<4, 3>), grid, wblock, 0, stm, p); break;
+        case 44: hipLaunchKernelGGL((k_stream_wave<4, 4>), grid, wblock, 0, stm, p); break;
+        case 82: hipLaunchKernelGGL((k_stream_wave<8, 2>), grid, wblock, 0, stm, p); break;
+        case 83: hipLaunchKernelGGL((k_stream_wave<8, 3>), grid, wblock, 0, stm, p); break;
+        default: return hipErrorInvalidValue;
+        }
+    }
+    else if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
     else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, 0, stm, p);
     return hipGetLastError();
 }

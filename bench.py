@@ -104,6 +104,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='detect416', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='images per GPU (default: the workload\'s)')
+    ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
+                    help='detect workloads: 2 = software pipeline (a step streams batch i and selects batch '
+                         'i-1 in one launch), 1 = every batch runs to completion before the next')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -133,12 +136,19 @@ def main():
         a.record(); b.record()
 
     if w['kind'] == 'detect':
+        # Software pipeline over the sequence of batches, as a serving loop would run the path: a
+        # step streams batch i and, inside the same launch, selects batch i-1 (yh_detect_pipelined).
+        # --in-flight 1 runs every batch to completion before the next (yh_detect).
+        lanes = 2 if args.in_flight > 1 else 1
         outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
+        pipe = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes']) if lanes > 1 else None
 
         def step(i, events=None):
+            if pipe is not None:
+                return pipe.submit(sets[i % ROTATE], stream_events=events)
             return hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs,
                              stream_events=events)
-        extra = {}
+        extra = {'batches_in_flight': lanes}
     else:
         gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
                for i in range(ROTATE)]
@@ -160,18 +170,31 @@ def main():
     for i in range(warmup):
         last = step(i)
     barrier()
+    if w['kind'] == 'detect' and lanes > 1:
+        # one batch at a time, for reference: every step waits for the one before it
+        n_serial = max(10, steps // 4)
+        t0 = time.perf_counter()
+        for i in range(n_serial):
+            hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
+        barrier()
+        extra['serial_ms_per_step'] = round(1e3 * (time.perf_counter() - t0) / n_serial, 5)
     t0 = time.perf_counter()
     for i in range(steps):
         if w['kind'] == 'detect' and i in ev:
-            last = step(i, (ev[i][0].cuda_event, ev[i][1].cuda_event))
+            last = step(i, ev[i])
         else:
             last = step(i)
+    enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
 
     if w['kind'] == 'detect':
+        if pipe is not None:
+            last = pipe.flush()                             # the last batch's select stage (outside the timed region,
+                                                            # which selected the last warm-up batch instead)
         if last.overflowed():
             raise SystemExit('candidate capacity overflow in the benchmark configuration')
+        extra['host_enqueue_ms_per_step'] = round(1e3 * enqueue / steps, 5)
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
         extra['detections_per_image_last_step'] = round(float(last.count.float().mean().item()), 2)
     else:
@@ -202,7 +225,7 @@ def main():
             ach = B * bytes_img / (kern_ms * 1e-3) / 1e9
             res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
-                                   kernel='k_stream<detect> (decode + score filter + compaction)',
+                                   kernel='k_stream_wave (decode + score filter + candidate compaction)',
                                    kernel_ms=round(kern_ms, 5), kernel_launches_timed=len(ev),
                                    algorithmic_bytes_per_launch=B * bytes_img,
                                    whole_pipeline_frac=round(value / world * bytes_img / 1e9 / HBM_PEAK_GBS, 4))

@@ -91,8 +91,10 @@ int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batc
  * the same arguments to the size query, can start from.  A workspace must not
  * be shared by calls that overlap in time.
  * max_candidates <= 2048 (with num_classes <= 1024, nms_max_boxes <= 128 and
- * num_classes * nms_max_boxes <= 4096) selects a single-launch form of the candidates -> detections stage; larger
- * capacities take a three-launch form.  Results are identical. */
+ * num_classes * nms_max_boxes <= 4096) selects a single-launch form of the
+ * candidates -> detections stage; larger capacities take a three-launch form.
+ * Results are identical.  The size also depends on the launch plan of the
+ * streaming pass, which the library derives from cfg and batch alone. */
 int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
                               int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);
 
@@ -128,6 +130,50 @@ int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_
                     int32_t *out_count, float *out_scores, float *out_boxes,
                     int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
                     int32_t *status, void *stream, void *event_begin, void *event_end);
+
+/* yh_detect as two calls that may go to two streams, so that the short
+ * candidates -> detections stage of one batch overlaps the streaming pass of
+ * the next (the caller orders them with events and gives batches that overlap
+ * different workspaces), or run on one stream back to back:
+ *   yh_detect_candidates  YOLOv3.py:338-357 / YOLOv2.py:183-199: decode and
+ *                         conf >= score_threshold filter; leaves the candidates
+ *                         (key and box) in the workspace;
+ *   yh_detect_select      YOLOv3.py:355-368 / YOLOv2.py:197-210: per-class NMS,
+ *                         gather, concat, from that workspace.
+ * Both take the arguments of the same name of yh_detect, with the same values
+ * for the pair; results are those of yh_detect. */
+int yh_detect_candidates(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                         float score_threshold, int32_t nms_max_boxes, int32_t max_candidates,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int yh_detect_select(const yh_head_config *cfg, int32_t batch,
+                     float iou_threshold, int32_t nms_max_boxes, int32_t max_candidates,
+                     void *workspace, size_t workspace_bytes,
+                     int32_t *out_count, float *out_scores, float *out_boxes,
+                     int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                     int32_t *status, void *stream);
+
+/* yh_detect software-pipelined over a sequence of equally shaped batches on ONE
+ * stream: call i streams batch i (yh_detect_candidates, into `workspace`) and
+ * selects batch i-1 (yh_detect_select, from `prev_workspace`, the workspace of
+ * call i-1, into the outputs) inside the same kernel launch, where the short
+ * latency-bound select stage hides behind the bandwidth-bound streaming pass.
+ *   prev_workspace == NULL : nothing to select (first call);
+ *   heads == NULL          : nothing to stream (drains the last batch).
+ * The outputs and status belong to batch i-1.  Both workspaces have
+ * workspace_bytes bytes; the caller alternates between two.  When the select
+ * stage's bounds do not allow it to ride in the streaming launch (see
+ * yh_detect_workspace_bytes: the single-launch form, and about 32 KiB of LDS,
+ * e.g. max_candidates <= 512 at 80 classes x 10 boxes) the two stages run one
+ * after the other, with the same results.  event_begin / event_end as in
+ * yh_detect_timed.  No counterpart in the reference, whose session.run is
+ * synchronous; results per batch are those of yh_detect. */
+int yh_detect_pipelined(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                        float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                        int32_t max_candidates, void *workspace, void *prev_workspace,
+                        size_t workspace_bytes,
+                        int32_t *out_count, float *out_scores, float *out_boxes,
+                        int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                        int32_t *status, void *stream, void *event_begin, void *event_end);
 
 /* The same pipeline entered after the decode: replaces YOLOv3.py:351-368 /
  * YOLOv2.py:193-210 on caller-supplied boxes [B][N][4] and conf [B][N][C].

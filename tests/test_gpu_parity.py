@@ -156,8 +156,7 @@ def test_detect_equals_decode_then_nms_at_full_size(gpu):
 
 
 def test_both_launch_shapes_agree(gpu, c_oracle):
-    """Capacity <= 512 finishes inside the streaming kernel, <= 2048 takes the
-    single-launch candidates -> detections stage,
+    """Capacity <= 2048 takes the single-launch candidates -> detections stage,
     a larger one the three-launch stage: identical results, and the same
     workspace can be reused call after call."""
     case = cases.v3()
@@ -170,6 +169,97 @@ def test_both_launch_shapes_agree(gpu, c_oracle):
             got = hd.detect(dheads, 0.5, 0.5, 10, max_candidates=cap, want_class_candidates=True)
             assert not got.overflowed()
             cases.same_detections(got.per_image(), want)
+
+
+@pytest.mark.parametrize('cap', [None, 2048, 5000])
+def test_pipelined_submit_matches_detect(gpu, cap):
+    """yh_detect_pipelined: batch i streams while batch i-1 is selected inside the same
+    launch (capacity 512), or right before it (larger capacities): detect()'s results,
+    batch after batch, on alternating workspaces."""
+    case = cases.v3()
+    hd = case.head_obj()
+    sets = [y.synth.torch_heads(gpu, 70 + i, 4, case.grids, case.P, case.C) for i in range(5)]
+    want = []
+    for h in sets:
+        w = hd.detect(h, 0.5, 0.5, 10, max_candidates=cap, want_class_candidates=True)
+        want.append((w.per_image(), w.class_candidates.clone()))
+    pipe = y.DetectPipeline(case.head_obj(), 0.5, 0.5, 10, max_candidates=cap, want_class_candidates=True)
+    got = []
+    for h in sets:
+        d = pipe.submit(h)
+        if d is not None:
+            got.append((d.per_image(), d.class_candidates.clone(), d.overflowed()))
+    d = pipe.flush()
+    got.append((d.per_image(), d.class_candidates.clone(), d.overflowed()))
+    assert pipe.flush() is None and len(got) == len(want)
+    for (gi, gc, ov), (wi, wc) in zip(got, want):
+        assert not ov
+        cases.same_detections(gi, wi)
+        for a, b in zip(gi, wi):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert torch.equal(gc, wc)
+    assert sum(len(g[0][0][0]) for g in got) > 0
+
+
+def test_candidates_then_select_calls(gpu):
+    """The two halves of yh_detect called one after the other through the C ABI."""
+    import ctypes
+    from yolo_tf_amd import _abi
+    case = cases.v3(size=160)
+    hd = case.head_obj()
+    heads = y.synth.torch_heads(gpu, 81, 3, case.grids, case.P, case.C, obj_mean=-1.0)
+    want = hd.detect(heads, 0.4, 0.5, 10, want_class_candidates=True)
+    (cfg, B, N, ws), = hd._plans.values()
+    cap = hd.default_max_candidates(N)
+    outs = hd._alloc_outputs(B, 10, gpu, True)
+    lib = _abi.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    for _ in range(2):
+        _abi.check(lib.yh_detect_candidates(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
+                                            0.4, 10, cap, ws.data_ptr(), ws.numel(), st))
+        _abi.check(lib.yh_detect_select(ctypes.byref(cfg), B, 0.5, 10, cap, ws.data_ptr(), ws.numel(),
+                                        *[t.data_ptr() for t in outs], st))
+    got = y.Detections(*outs, None)
+    assert int(got.count.sum()) > 0 and not got.overflowed()
+    cases.same_detections(got.per_image(), want.per_image())
+    assert torch.equal(got.class_candidates, want.class_candidates)
+
+
+def test_streaming_variants_agree(gpu, monkeypatch):
+    """The wave-private streaming kernel (4 and 8 KiB tiles, 2..4 buffers, few and many
+    work units) and the workgroup-tile kernel find the same candidates."""
+    case = cases.v3(size=160)
+    heads = case.heads(77, 3, obj_mean=-1.0)
+    dheads = to_dev(heads, gpu)
+    ref = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+    want, want_cc = ref.per_image(), ref.class_candidates.clone()
+    assert int(ref.count.sum()) > 0
+    for ni, nbuf, units in (('8', '3', '8192'), ('8', '2', '64'), ('4', '2', '300'), ('4', '3', '7'),
+                            ('4', '4', '100000'), ('1', '3', '8192')):
+        monkeypatch.setenv('YH_STREAM_NI', ni)
+        monkeypatch.setenv('YH_STREAM_NBUF', nbuf)
+        monkeypatch.setenv('YH_STREAM_UNITS', units)
+        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+        assert not got.overflowed()
+        cases.same_detections(got.per_image(), want)
+        assert torch.equal(got.class_candidates, want_cc)
+
+
+def test_rows_wider_than_a_wave_tile(gpu):
+    """2100 classes: one row (8420 B) does not fit the wave-private tiles, the
+    workgroup-tile kernel takes over; 600 classes: several 64-lane passes per row."""
+    for C, thr in ((2100, 0.3), (600, 0.3)):
+        grids = [(3, 2), (2, 2)]
+        rng = np.random.Generator(np.random.PCG64(5))
+        priors = [rng.uniform(0.5, 3.0, size=(2, 2)).astype(np.float32) for _ in grids]
+        case = cases.Case('wide', grids, priors, (32.0, 16.0), (32.0, 16.0), C, 64, 3)
+        dheads = to_dev(case.heads(78, 2, obj_mean=1.0, hot_mean=1.0), gpu)
+        hd = case.head_obj()
+        fused = hd.detect(dheads, thr, 0.5, 5, want_class_candidates=True).resolved()
+        staged = hd.nms(*hd.decode(dheads), thr, 0.5, 5, want_class_candidates=True).resolved()
+        assert int(fused.count.sum()) > 0
+        cases.same_detections(fused.per_image(), staged.per_image())
+        assert torch.equal(fused.class_candidates, staged.class_candidates)
 
 
 def test_detect_is_deterministic(gpu):

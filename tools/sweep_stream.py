@@ -35,7 +35,7 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        e = (evs[i][0].cuda_event, evs[i][1].cuda_event) if i in evs else None
+        e = evs[i] if i in evs else None
         r = hd.detect(sets[i % 4], 0.5, 0.5, 10, max_candidates=2048, outputs=outs, stream_events=e)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0

@@ -61,6 +61,11 @@ SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     'yh_detect_timed': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, ctypes.c_size_t,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'yh_detect_pipelined': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, _P, ctypes.c_size_t,
+                                           _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'yh_detect_candidates': (ctypes.c_int, [_CFG, _PP, _I, _F, _I, _I, _P, ctypes.c_size_t, _P]),
+    'yh_detect_select': (ctypes.c_int, [_CFG, _I, _F, _I, _I, _P, ctypes.c_size_t,
+                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     'yh_nms_workspace_bytes': (ctypes.c_int, [_I, ctypes.c_int64, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)]),
     'yh_nms': (ctypes.c_int, [_I, ctypes.c_int64, _I, _P, _P, _F, _F, _I, _I, _P, ctypes.c_size_t,
                               _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -358,31 +358,45 @@ static int run_pipeline(const yh::StreamParams &p, yh::StreamMode mode, uint32_t
     return YH_OK;
 }
 
-static int detect_impl(const yh_head_config *cfg, const float *const *heads, int32_t batch,
-              float score_threshold, float iou_threshold, int32_t nms_max_boxes,
-              int32_t max_candidates, void *workspace, size_t workspace_bytes,
-              int32_t *out_count, float *out_scores, float *out_boxes,
-              int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
-              int32_t *status, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end)
+// Everything yh_detect derives from its arguments.  heads == nullptr: only the
+// candidates -> detections stage is wanted; out_count == nullptr: only the
+// streaming pass.
+struct DetectPlan {
+    yh::StreamParams p;
+    yh::NmsParams q;
+    uint32_t blocks;
+};
+
+static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float *const *heads, bool want_stream,
+                          bool want_select, int32_t batch, float score_threshold, float iou_threshold,
+                          int32_t nms_max_boxes, int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                          int32_t *out_count, float *out_scores, float *out_boxes, int32_t *out_class,
+                          int32_t *out_index, int32_t *out_class_candidates, int32_t *status)
 {
     int rc = check_config(cfg);
     if (rc != YH_OK) return rc;
-    if ((rc = check_nms_args(batch, iou_threshold, nms_max_boxes, max_candidates, workspace, out_count,
-                             out_scores, out_boxes, out_class, out_index, status)) != YH_OK)
-        return rc;
+    if (want_select) {
+        rc = check_nms_args(batch, iou_threshold, nms_max_boxes, max_candidates, workspace, out_count,
+                            out_scores, out_boxes, out_class, out_index, status);
+    } else {
+        int32_t dummy = 0;                    // the output pointers are not part of this call
+        rc = check_nms_args(batch, 0.5f, nms_max_boxes, max_candidates, workspace, &dummy, &dummy, &dummy,
+                            &dummy, &dummy, &dummy);
+    }
+    if (rc != YH_OK) return rc;
     if (batch == 0) return YH_OK;
-    if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (reinterpret_cast<uintptr_t>(out_boxes) & 15u))
-        return fail(YH_ERR_ALIGN, "workspace must be 256-byte and out_boxes 16-byte aligned");
+    if (want_stream && (rc = check_heads(cfg, heads)) != YH_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail(YH_ERR_ALIGN, "workspace must be 256-byte aligned");
+    if (want_select && (reinterpret_cast<uintptr_t>(out_boxes) & 15u))
+        return fail(YH_ERR_ALIGN, "out_boxes must be 16-byte aligned");
     const int64_t N = boxes_per_image(cfg);
-    yh::StreamParams p;
-    fill_stream_from_config(p, cfg, heads, batch);
-    const uint32_t blocks = plan_stream(p, batch, yh::kModeDetect);
+    yh::StreamParams &p = d.p;
+    fill_stream_from_config(p, cfg, want_stream ? heads : nullptr, batch);
+    d.blocks = plan_stream(p, batch, yh::kModeDetect);
     const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true, p.upi);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
 
     p.thr = score_threshold;
     p.prefilter = prefilter_logit(score_threshold);
@@ -393,17 +407,32 @@ static int detect_impl(const yh_head_config *cfg, const float *const *heads, int
     p.cand_box = w.cand_box;
     p.ukeys = w.ukeys;
     p.uboxes = w.uboxes;
-    yh::NmsParams q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
-                                      nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
-                                      out_class, out_index, out_class_candidates, status);
+    d.q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
+                          nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
+                          out_class, out_index, out_class_candidates, status);
     if (p.wave_ni) {                          // candidates arrive with slot-indexed boxes
-        q.upi = p.upi;
-        q.ukeys = w.ukeys;
-        q.uboxes = w.uboxes;
-        q.cand_box = w.cand_box;
-        q.boxes_fill = w.boxes;
+        d.q.upi = p.upi;
+        d.q.ukeys = w.ukeys;
+        d.q.uboxes = w.uboxes;
+        d.q.cand_box = w.cand_box;
+        d.q.boxes_fill = w.boxes;
     }
-    return run_pipeline(p, yh::kModeDetect, blocks, q, st, ev_begin, ev_end);
+    return YH_OK;
+}
+
+static int detect_impl(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+              float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+              int32_t max_candidates, void *workspace, size_t workspace_bytes,
+              int32_t *out_count, float *out_scores, float *out_boxes,
+              int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+              int32_t *status, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    DetectPlan d;
+    const int rc = detect_prepare(d, cfg, heads, true, true, batch, score_threshold, iou_threshold, nms_max_boxes,
+                                  max_candidates, workspace, workspace_bytes, out_count, out_scores, out_boxes,
+                                  out_class, out_index, out_class_candidates, status);
+    if (rc != YH_OK || batch == 0) return rc;
+    return run_pipeline(d.p, yh::kModeDetect, d.blocks, d.q, static_cast<hipStream_t>(stream), ev_begin, ev_end);
 }
 
 int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batch,
@@ -429,6 +458,75 @@ int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_
                        workspace, workspace_bytes, out_count, out_scores, out_boxes, out_class, out_index,
                        out_class_candidates, status, stream, static_cast<hipEvent_t>(event_begin),
                        static_cast<hipEvent_t>(event_end));
+}
+
+int yh_detect_candidates(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                         float score_threshold, int32_t nms_max_boxes, int32_t max_candidates,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    DetectPlan d;
+    const int rc = detect_prepare(d, cfg, heads, true, false, batch, score_threshold, 0.5f, nms_max_boxes,
+                                  max_candidates, workspace, workspace_bytes, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr);
+    if (rc != YH_OK || batch == 0) return rc;
+    const hipError_t e = yh::launch_stream(d.p, yh::kModeDetect, d.blocks, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "stream launch");
+    return YH_OK;
+}
+
+int yh_detect_select(const yh_head_config *cfg, int32_t batch,
+                     float iou_threshold, int32_t nms_max_boxes, int32_t max_candidates,
+                     void *workspace, size_t workspace_bytes,
+                     int32_t *out_count, float *out_scores, float *out_boxes,
+                     int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                     int32_t *status, void *stream)
+{
+    DetectPlan d;
+    const int rc = detect_prepare(d, cfg, nullptr, false, true, batch, 0.5f, iou_threshold, nms_max_boxes,
+                                  max_candidates, workspace, workspace_bytes, out_count, out_scores, out_boxes,
+                                  out_class, out_index, out_class_candidates, status);
+    if (rc != YH_OK || batch == 0) return rc;
+    const hipError_t e = yh::launch_nms_pipeline(d.q, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "nms launch");
+    return YH_OK;
+}
+
+int yh_detect_pipelined(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                        float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                        int32_t max_candidates, void *workspace, void *prev_workspace, size_t workspace_bytes,
+                        int32_t *out_count, float *out_scores, float *out_boxes,
+                        int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                        int32_t *status, void *stream, void *event_begin, void *event_end)
+{
+    if (heads && prev_workspace && workspace == prev_workspace)
+        return fail(YH_ERR_INVALID_ARG, "workspace and prev_workspace must differ");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t ev_b = static_cast<hipEvent_t>(event_begin), ev_e = static_cast<hipEvent_t>(event_end);
+    DetectPlan cur, prev;
+    int rc;
+    if (heads) {
+        rc = detect_prepare(cur, cfg, heads, true, false, batch, score_threshold, 0.5f, nms_max_boxes,
+                            max_candidates, workspace, workspace_bytes, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr);
+        if (rc != YH_OK) return rc;
+    }
+    if (prev_workspace) {
+        rc = detect_prepare(prev, cfg, nullptr, false, true, batch, 0.5f, iou_threshold, nms_max_boxes,
+                            max_candidates, prev_workspace, workspace_bytes, out_count, out_scores, out_boxes,
+                            out_class, out_index, out_class_candidates, status);
+        if (rc != YH_OK) return rc;
+    }
+    if (batch == 0 || (!heads && !prev_workspace)) return YH_OK;
+    hipError_t e;
+    const bool fuse = heads && prev_workspace && cur.p.wave_ni && yh::select_fits_stream(prev.q);
+    if (prev_workspace && !fuse && (e = yh::launch_nms_pipeline(prev.q, st)) != hipSuccess) return hip_fail(e, "nms launch");
+    if (heads) {
+        if (ev_b && (e = hipEventRecord(ev_b, st)) != hipSuccess) return hip_fail(e, "event record");
+        e = yh::launch_stream(cur.p, yh::kModeDetect, cur.blocks, st, fuse ? &prev.q : nullptr);
+        if (e != hipSuccess) return hip_fail(e, "stream launch");
+        if (ev_e && (e = hipEventRecord(ev_e, st)) != hipSuccess) return hip_fail(e, "event record");
+    }
+    return YH_OK;
 }
 
 int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,

@@ -91,7 +91,10 @@ constexpr int kTileFloats = 8192;                   // LDS tile of the streaming
 
 enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
 
-hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t st);
+// fused: a candidates -> detections stage (of the previous batch) to run inside the same launch, one
+// extra single-wavefront workgroup per image; only with the wave-private variant and select_fits_stream()
+hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t st,
+                         const struct NmsParams *fused = nullptr);
 
 // ---- candidates -> detections --------------------------------------------
 struct NmsParams {
@@ -129,8 +132,11 @@ constexpr int kPostRankMax = 1024;      // up to here: rank sort; above: bitonic
 constexpr int kPostMaxClasses = 1024;
 constexpr int kPostMaxBoxes = 128;
 constexpr int kPostKeptMax = 4096;      // num_classes * nms_max_boxes
+constexpr int kPostThreads = 1024;      // workgroup of the stand-alone kernel
+constexpr size_t kFuseLdsMax = 32 * 1024;   // largest LDS block of the stage when it rides in the streaming launch
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
+bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
 
 // ---- loss ------------------------------------------------------------------
 struct LossScale {

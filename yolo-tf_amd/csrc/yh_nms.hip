@@ -17,28 +17,16 @@ constexpr int kBinThreads = 1024;
 constexpr int kSegThreads = 256;
 constexpr int kSortLds = 2048;       // keys sorted in LDS by k_sort_nms; longer segments sort in global memory
 constexpr int kFinThreads = 256;
-constexpr int kPostThreads = 1024;
 
 // ------------------------------------------------------------------ k_post
-// Dynamic LDS: (kPostThreads / 64) * max_boxes * 5 floats.
+// All LDS is dynamic and sized by the call's bounds (capacity, classes, boxes per
+// class), not by the kernel's limits: with a small capacity a workgroup fits into
+// a compute unit next to the streaming kernel's workgroups, so that on a second
+// stream it overlaps the next batch's streaming pass instead of waiting behind it.
 __global__ __launch_bounds__(kPostThreads) void k_post(const NmsParams p)
 {
-    extern __shared__ __align__(16) float s_kbox_all[];
-    __shared__ unsigned long long s_keys[kPostCap];
-    __shared__ unsigned long long s_sorted[kPostRankMax];
-    __shared__ float4 s_ubox[kPostCap];
-    __shared__ float4 s_box[kPostRankMax];
-    __shared__ uint16_t s_kpos[kPostKeptMax];
-    __shared__ int s_off[kPostMaxClasses];
-    __shared__ int s_seg[kPostMaxClasses];
-    __shared__ int s_cnt[kPostMaxClasses];
-    __shared__ int s_kept[kPostMaxClasses];
-    __shared__ int s_wave[kPostThreads / 64];
-    __shared__ int s_total;
-    PostLds l;
-    l.keys = s_keys; l.sorted = s_sorted; l.ubox = s_ubox; l.box = s_box; l.kpos = s_kpos;
-    l.off = s_off; l.seg = s_seg; l.cnt = s_cnt; l.kept = s_kept; l.wave_sums = s_wave; l.total = &s_total; l.kbox_all = s_kbox_all;
-    post_image<kPostThreads, kPostMaxClasses / kPostThreads>(p, blockIdx.x, l, kPostRankMax);
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    post_image_dyn<kPostThreads>(p, blockIdx.x, s_raw);
 }
 
 // ------------------------------------------------ general path: bin, sort+nms, finalize
@@ -179,12 +167,27 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p)
     if (tid == 0) p.out_count[b] = s_off[C - 1] + kept[C - 1];
 }
 
+static bool single_launch_shape(const NmsParams &p)
+{
+    return p.cand_cap <= kPostCap && p.C <= kPostMaxClasses && p.max_boxes <= kPostMaxBoxes &&
+           p.C * p.max_boxes <= kPostKeptMax;
+}
+
+bool select_fits_stream(const NmsParams &p)
+{
+    return single_launch_shape(p) && post_layout(p.cand_cap, p.C, p.max_boxes, 64).bytes <= kFuseLdsMax;
+}
+
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;
-    if (p.cand_cap <= kPostCap && p.C <= kPostMaxClasses && p.max_boxes <= kPostMaxBoxes &&
-        p.C * p.max_boxes <= kPostKeptMax) {
-        const size_t lds = (size_t)(kPostThreads / 64) * p.max_boxes * 5 * sizeof(float);
+    if (single_launch_shape(p)) {
+        const size_t lds = post_layout(p.cand_cap, p.C, p.max_boxes, kPostThreads).bytes;
+        if (lds > 48 * 1024) {                // beyond the default limit of dynamic LDS
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_post),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_post, dim3(p.B), dim3(kPostThreads), lds, stm, p);
         return hipGetLastError();
     }

@@ -117,14 +117,28 @@ __device__ inline void cand_for_each(const NmsParams &p, int b, int list_raw, F 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned long long *uk = p.ukeys + (long long)b * nslots;
     const float4 *ub = reinterpret_cast<const float4 *>(p.uboxes) + (long long)b * nslots;
-    for (int e = tid; e < nslots; e += THREADS) {
-        const unsigned long long k = uk[e];
-        float4 box = zero;
-        if (WANT_BOX) {
-            box = ub[e];
-            asm volatile("" ::"v"(box.x));                    // keeps the load next to the key's, ahead of the test
+    // U slots per thread are requested back to back (keys and boxes alike, valid or not: an
+    // image's slots are a few tens of KiB), so that a small workgroup still pays one memory
+    // round trip per U * THREADS slots instead of one per slot.
+    constexpr int U = THREADS >= 1024 ? 2 : (THREADS >= 128 ? 2048 / THREADS : 32);
+    for (int e0 = 0; e0 < nslots; e0 += THREADS * U) {
+        unsigned long long k[U];
+        float4 box[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * THREADS + tid;
+            const int ec = e < nslots ? e : nslots - 1;
+            k[u] = uk[ec];
+            box[u] = WANT_BOX ? ub[ec] : zero;
+            if (e >= nslots) k[u] = kEmptySlot;
         }
-        if (k != kEmptySlot) f(k, box);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (WANT_BOX) asm volatile("" ::"v"(box[u].x));   // keeps the box loads up there with the keys'
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k[u] != kEmptySlot) f(k[u], box[u]);
     }
     const int nl = list_raw < p.cand_cap ? list_raw : p.cand_cap;
     const unsigned long long *cand = p.cand + (long long)b * p.cand_cap;
@@ -239,33 +253,75 @@ struct PostLds {
     unsigned long long *sorted;   // [rank_max]
     float4 *ubox;                 // [cap] boxes of keys[]
     float4 *box;                  // [rank_max] boxes of sorted[]
+    uint16_t *mask;               // [cap] short segments: bit j = "candidate j of my segment would suppress me"
     uint16_t *kpos;               // [C * max_boxes]
     int *off, *seg, *cnt, *kept;  // [C] each
     int *wave_sums;               // [THREADS / 64]
-    int *total;                   // [1]
+    int *total;                   // [2]: candidates found, "a segment is longer than kLaneNmsMax"
     float *kbox_all;              // [THREADS / 64][max_boxes][5]
 };
 
-constexpr int kNmsGroup = 16;     // lanes that share one short class segment (== kLaneNmsMax)
+// Ranks of KPT keys per thread against all M keys (keys are unique): the list is
+// read once per thread, as broadcast LDS reads, several in flight.
+template <int THREADS, int KPT>
+__device__ __forceinline__ void rank_sort_pass(const PostLds &l, int M, int i0)
+{
+    const int tid = threadIdx.x;
+    unsigned long long key[KPT];
+    int rank[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = i0 + u * THREADS + tid;
+        key[u] = i < M ? l.keys[i] : 0ull;
+        rank[u] = 0;
+    }
+    int j = 0;
+    for (; j + 4 <= M; j += 4) {
+        const unsigned long long k0 = l.keys[j], k1 = l.keys[j + 1], k2 = l.keys[j + 2], k3 = l.keys[j + 3];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+            rank[u] += (k0 < key[u] ? 1 : 0) + (k1 < key[u] ? 1 : 0) + (k2 < key[u] ? 1 : 0) + (k3 < key[u] ? 1 : 0);
+    }
+    for (; j < M; ++j) {
+        const unsigned long long k0 = l.keys[j];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) rank[u] += k0 < key[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = i0 + u * THREADS + tid;
+        if (i < M) {
+            l.sorted[rank[u]] = key[u];
+            l.box[rank[u]] = l.ubox[i];
+        }
+    }
+}
 
-// Candidates of image b -> its detections, by one workgroup of THREADS threads,
-// everything in LDS between the candidate slots and the outputs: keys and boxes
-// loaded together, keys sorted by the full key (class ascending, score
-// descending, row ascending; rank sort up to rank_max keys, bitonic beyond) with
-// the boxes following them, the class segments walked by groups of 16 lanes
-// (short ones) or wavefronts, the selections concatenated (YOLOv3.py:362-367).
-// C <= THREADS * SCAN_ITEMS.  Zeroes img_count[b] for the next call.
+// Candidates of image b -> its detections, by one workgroup of THREADS threads
+// (64 .. 1024), everything in LDS between the candidate slots and the outputs:
+// keys and boxes loaded together, keys sorted by the full key (class ascending,
+// score descending, row ascending; rank sort up to rank_max keys, bitonic
+// beyond) with the boxes following them, per-class greedy NMS, the selections
+// concatenated (YOLOv3.py:362-367).  C <= THREADS * SCAN_ITEMS.  Zeroes
+// img_count[b] for the next call.
+//
+// NMS of the short class segments (<= kLaneNmsMax candidates, the usual case at
+// detection thresholds) runs in two data-parallel steps: one thread per CANDIDATE
+// collects the bits "the earlier candidate j of my segment would suppress me";
+// then one thread per CLASS walks its segment in score order over those bits, a
+// few integer operations per candidate.  Longer segments take a wavefront each
+// (wave_nms).
 template <int THREADS, int SCAN_ITEMS>
 __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, int rank_max)
 {
-    static_assert(kNmsGroup == kLaneNmsMax, "one lane per candidate of a short segment");
+    static_assert(kLaneNmsMax <= 16, "suppression bits of a short segment are kept in 16 bits");
     const int tid = threadIdx.x, wave = tid >> 6, C = p.C, mb = p.max_boxes, cap = p.cand_cap;
     const int raw = p.img_count[b];
     for (int c = tid; c < C; c += THREADS) { l.cnt[c] = 0; l.kept[c] = 0; }
-    if (tid == 0) *l.total = 0;
+    if (tid < 2) l.total[tid] = 0;
     __syncthreads();
     cand_for_each<THREADS, true>(p, b, raw, [&](unsigned long long k, float4 box) {
-        const int pos = atomicAdd(l.total, 1);
+        const int pos = atomicAdd(&l.total[0], 1);
         if (pos < cap) {
             l.keys[pos] = k;
             l.ubox[pos] = box;
@@ -273,7 +329,7 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
         }
     });
     __syncthreads();
-    const int found = *l.total;
+    const int found = l.total[0];
     const int M = found < cap ? found : cap;
     if (tid == 0) {
         p.img_count[b] = 0;                                   // leaves the counter clean for the next call
@@ -283,21 +339,11 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     const unsigned long long *sorted;
     const float4 *sbox;
     if (M <= rank_max) {
-        // rank sort, four lanes per key: each counts the smaller keys in a quarter of the list
-        const int q = tid & 3;
-        const int j0 = (M * q) >> 2, j1 = (M * (q + 1)) >> 2;
-        for (int i0 = 0; i0 < M; i0 += THREADS / 4) {
-            const int i = i0 + (tid >> 2);
-            const unsigned long long key = i < M ? l.keys[i] : 0ull;
-            int rank = 0;
-            for (int j = j0; j < j1; ++j) rank += l.keys[j] < key ? 1 : 0;   // keys are unique
-            rank += __shfl_xor(rank, 1, 64);
-            rank += __shfl_xor(rank, 2, 64);
-            if (i < M && q == 0) {
-                l.sorted[rank] = key;
-                l.box[rank] = l.ubox[i];
-            }
-        }
+        if (M <= THREADS) rank_sort_pass<THREADS, 1>(l, M, 0);
+        else if (M <= 2 * THREADS) rank_sort_pass<THREADS, 2>(l, M, 0);
+        else if (M <= 4 * THREADS) rank_sort_pass<THREADS, 4>(l, M, 0);
+        else
+            for (int i0 = 0; i0 < M; i0 += 8 * THREADS) rank_sort_pass<THREADS, 8>(l, M, i0);
         __syncthreads();
         sorted = l.sorted;
         sbox = l.box;
@@ -311,6 +357,7 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     for (int c = tid; c < C; c += THREADS) {
         const int n = l.cnt[c];
         l.off[c] = n;
+        if (n > kLaneNmsMax) l.total[1] = 1;
         if (p.out_class_candidates) p.out_class_candidates[b * C + c] = n;
     }
     __syncthreads();
@@ -318,68 +365,124 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     for (int c = tid; c < C; c += THREADS) l.seg[c] = l.off[c];
     __syncthreads();
 
-    // Short segments (the usual case at detection thresholds): a group of 16 lanes per
-    // class, one lane per candidate.  Lane i collects the bits "the earlier candidate j
-    // would suppress me"; the greedy walk over those bits is then a few integer steps,
-    // done redundantly by every lane of the group.
-    {
-        const int gl = tid & (kNmsGroup - 1);
-        for (int c = tid / kNmsGroup; c < C; c += THREADS / kNmsGroup) {
-            const int cnt = l.cnt[c];
-            if (cnt == 0 || cnt > kLaneNmsMax) continue;
-            const int off = l.seg[c];
-            const bool valid = gl < cnt;
-            const float4 bi = sbox[off + (valid ? gl : 0)];
-            const float ymin = fminf(bi.x, bi.z), xmin = fminf(bi.y, bi.w);
-            const float ymax = fmaxf(bi.x, bi.z), xmax = fmaxf(bi.y, bi.w);
-            const float area = (ymax - ymin) * (xmax - xmin);
-            uint32_t mymask = 0;
-            for (int j = 0; j + 1 < cnt; ++j) {
-                const float4 bj = sbox[off + j];
-                const float jy0 = fminf(bj.x, bj.z), jx0 = fminf(bj.y, bj.w);
-                const float jy1 = fmaxf(bj.x, bj.z), jx1 = fmaxf(bj.y, bj.w);
-                if (valid && gl > j &&
-                    suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, (jy1 - jy0) * (jx1 - jx0), p.iou_thr))
-                    mymask |= 1u << j;
-            }
-            uint32_t keepmask = 0;
-            int kept = 0;
-            for (int j = 0; j < cnt && kept < mb; ++j) {
-                const uint32_t mj = (uint32_t)__shfl((int)mymask, j, kNmsGroup);
-                if ((mj & keepmask) == 0u) { keepmask |= 1u << j; ++kept; }
-            }
-            if ((keepmask >> gl) & 1u) l.kpos[c * mb + __popc(keepmask & ((1u << gl) - 1u))] = (uint16_t)(off + gl);
-            if (gl == 0) l.kept[c] = kept;
+    // short segments, step 1: a thread per candidate
+    for (int i = tid; i < M; i += THREADS) {
+        const int c = key_class(sorted[i]);
+        if (l.cnt[c] > kLaneNmsMax) continue;
+        const int off = l.seg[c];
+        const float4 bi = sbox[i];
+        const float ymin = fminf(bi.x, bi.z), xmin = fminf(bi.y, bi.w);
+        const float ymax = fmaxf(bi.x, bi.z), xmax = fmaxf(bi.y, bi.w);
+        const float area = (ymax - ymin) * (xmax - xmin);
+        uint32_t m = 0;
+        for (int j = off; j < i; ++j) {
+            const float4 bj = sbox[j];
+            const float jy0 = fminf(bj.x, bj.z), jx0 = fminf(bj.y, bj.w);
+            const float jy1 = fmaxf(bj.x, bj.z), jx1 = fmaxf(bj.y, bj.w);
+            if (suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, (jy1 - jy0) * (jx1 - jx0), p.iou_thr))
+                m |= 1u << (j - off);
         }
+        l.mask[i] = (uint16_t)m;
+    }
+    __syncthreads();
+    // step 2: a thread per class; a candidate is selected iff no SELECTED earlier one suppresses it
+    for (int c = tid; c < C; c += THREADS) {
+        const int cnt = l.cnt[c];
+        if (cnt == 0 || cnt > kLaneNmsMax) continue;
+        const int off = l.seg[c];
+        uint16_t *kp = l.kpos + c * mb;
+        uint32_t keepmask = 0;
+        int kept = 0;
+        for (int j = 0; j < cnt && kept < mb; ++j) {
+            if ((l.mask[off + j] & keepmask) == 0u) {
+                keepmask |= 1u << j;
+                kp[kept++] = (uint16_t)(off + j);
+            }
+        }
+        l.kept[c] = kept;
     }
     // longer segments: one wavefront per class
-    float (*kbox)[5] = reinterpret_cast<float (*)[5]>(l.kbox_all + (size_t)wave * mb * 5);
-    for (int c = wave; c < C; c += THREADS / 64) {
-        const int cnt = l.cnt[c];
-        if (cnt <= kLaneNmsMax) continue;
-        const int off = l.seg[c];
-        const int kept = wave_nms<true>(sorted + off, cnt, nullptr, sbox + off, kbox, p.iou_thr, mb,
-                                        nullptr, nullptr, l.kpos + c * mb, off);
-        if ((tid & 63) == 0) l.kept[c] = kept;
+    if (l.total[1]) {
+        float (*kbox)[5] = reinterpret_cast<float (*)[5]>(l.kbox_all + (size_t)wave * mb * 5);
+        for (int c = wave; c < C; c += THREADS / 64) {
+            const int cnt = l.cnt[c];
+            if (cnt <= kLaneNmsMax) continue;
+            const int off = l.seg[c];
+            const int kept = wave_nms<true>(sorted + off, cnt, nullptr, sbox + off, kbox, p.iou_thr, mb,
+                                            nullptr, nullptr, l.kpos + c * mb, off);
+            if ((tid & 63) == 0) l.kept[c] = kept;
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += THREADS) l.off[c] = l.kept[c];
     __syncthreads();
     block_exclusive_scan<THREADS, SCAN_ITEMS>(l.off, C, l.wave_sums);
-    const int ocap = C * mb;
-    for (int e = tid; e < ocap; e += THREADS) {
-        const int c = e / mb, j = e - c * mb;
-        if (j < l.kept[c]) {
-            const int pos = l.kpos[e];
+    const long long obase = (long long)b * C * mb;
+    for (int c = tid; c < C; c += THREADS) {                   // a thread per class writes its selections
+        const int kept = l.kept[c];
+        const long long dst0 = obase + l.off[c];
+        for (int j = 0; j < kept; ++j) {
+            const int pos = l.kpos[c * mb + j];
             const unsigned long long key = sorted[pos];
-            const long long dst = (long long)b * ocap + l.off[c] + j;
-            p.out_scores[dst] = key_score(key);
-            reinterpret_cast<float4 *>(p.out_boxes)[dst] = sbox[pos];
-            p.out_class[dst] = c;
-            p.out_index[dst] = key_row(key);
+            p.out_scores[dst0 + j] = key_score(key);
+            reinterpret_cast<float4 *>(p.out_boxes)[dst0 + j] = sbox[pos];
+            p.out_class[dst0 + j] = c;
+            p.out_index[dst0 + j] = key_row(key);
         }
     }
     if (tid == 0) p.out_count[b] = l.off[C - 1] + l.kept[C - 1];
+}
+
+// LDS layout of post_image for a call's bounds (capacity, classes, boxes per class)
+// and a workgroup size; every array 16-byte aligned.
+struct PostLayout {
+    size_t keys, sorted, ubox, box, mask, kpos, off, seg, cnt, kept, wave, total, kbox, bytes;
+    int rank_max;
+};
+
+__host__ __device__ inline PostLayout post_layout(int cap, int C, int mb, int threads)
+{
+    PostLayout L;
+    L.rank_max = cap < kPostRankMax ? cap : kPostRankMax;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+    L.ubox = take((size_t)cap * 16);
+    L.box = take((size_t)L.rank_max * 16);
+    L.keys = take((size_t)cap * 8);
+    L.sorted = take((size_t)L.rank_max * 8);
+    L.kbox = take((size_t)(threads / 64) * mb * 5 * 4);
+    L.off = take((size_t)C * 4);
+    L.seg = take((size_t)C * 4);
+    L.cnt = take((size_t)C * 4);
+    L.kept = take((size_t)C * 4);
+    L.wave = take((size_t)(threads / 64) * 4);
+    L.total = take(8);
+    L.mask = take((size_t)cap * 2);
+    L.kpos = take((size_t)C * mb * 2);
+    L.bytes = o;
+    return L;
+}
+
+// post_image on a raw LDS block of post_layout(...).bytes bytes.
+template <int THREADS>
+__device__ inline void post_image_dyn(const NmsParams &p, int b, unsigned char *raw)
+{
+    const PostLayout L = post_layout(p.cand_cap, p.C, p.max_boxes, THREADS);
+    PostLds l;
+    l.keys = reinterpret_cast<unsigned long long *>(raw + L.keys);
+    l.sorted = reinterpret_cast<unsigned long long *>(raw + L.sorted);
+    l.ubox = reinterpret_cast<float4 *>(raw + L.ubox);
+    l.box = reinterpret_cast<float4 *>(raw + L.box);
+    l.mask = reinterpret_cast<uint16_t *>(raw + L.mask);
+    l.kpos = reinterpret_cast<uint16_t *>(raw + L.kpos);
+    l.off = reinterpret_cast<int *>(raw + L.off);
+    l.seg = reinterpret_cast<int *>(raw + L.seg);
+    l.cnt = reinterpret_cast<int *>(raw + L.cnt);
+    l.kept = reinterpret_cast<int *>(raw + L.kept);
+    l.wave_sums = reinterpret_cast<int *>(raw + L.wave);
+    l.total = reinterpret_cast<int *>(raw + L.total);
+    l.kbox_all = reinterpret_cast<float *>(raw + L.kbox);
+    post_image<THREADS, kPostMaxClasses / THREADS>(p, b, l, L.rank_max);
 }
 
 }  // namespace yh

@@ -23,7 +23,8 @@
 // the image's candidate list; the launch is oversubscribed (a few thousand
 // short workgroups) so that this latency-bound tail overlaps other workgroups'
 // streaming.
-#include "yh_internal.h"
+#include <cstring>
+#include "yh_post.h"
 
 namespace yh {
 
@@ -311,15 +312,27 @@ __device__ __forceinline__ void wave_flush(const WaveOut &o, const unsigned long
     count = 0;
 }
 
+// LDS of a streaming workgroup: NBUF tiles, then the staged boxes and keys.
+constexpr size_t wave_lds_bytes(int ni, int nbuf) { return (size_t)nbuf * ni * 1024 + (size_t)kWaveStage * (16 + 8); }
+
+// The first q.B workgroups of the launch do not stream: each runs the candidates ->
+// detections stage of one image of the PREVIOUS batch (q; its candidates were left in
+// another workspace by the launch before this one on the same stream), so that the
+// latency-bound stage hides behind this batch's streaming instead of following it.
 template <int NI, int NBUF>
-__global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p)
+__global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const NmsParams q)
 {
     constexpr int kBuf = NI * 256;                            // floats per tile buffer
-    __shared__ __attribute__((aligned(16))) float s_tile[NBUF][kBuf];
-    __shared__ __attribute__((aligned(16))) float4 s_box[kWaveStage];
-    __shared__ unsigned long long s_keys[kWaveStage];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    if (blockIdx.x < (uint32_t)q.B) {
+        post_image_dyn<64>(q, (int)blockIdx.x, s_dyn);
+        return;
+    }
+    float (*s_tile)[kBuf] = reinterpret_cast<float (*)[kBuf]>(s_dyn);
+    float4 *s_box = reinterpret_cast<float4 *>(s_dyn + (size_t)NBUF * kBuf * 4);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(s_dyn + (size_t)NBUF * kBuf * 4 + (size_t)kWaveStage * 16);
     const int lane = threadIdx.x;
-    const uint32_t unit = blockIdx.x;
+    const uint32_t unit = blockIdx.x - (uint32_t)q.B;
 
     int s = 0;
 #pragma unroll
@@ -446,8 +459,26 @@ __global__ __launch_bounds__(kThreads) void k_decode_full(const StreamParams p, 
     }
 }
 
-hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t stm)
+template <int NI, int NBUF>
+static hipError_t launch_wave(const StreamParams &p, uint32_t blocks, hipStream_t stm, const NmsParams &q)
 {
+    size_t lds = wave_lds_bytes(NI, NBUF);
+    if (q.B > 0) {
+        const size_t need = post_layout(q.cand_cap, q.C, q.max_boxes, 64).bytes;
+        lds = need > lds ? need : lds;
+    }
+    if (lds > 48 * 1024) {                    // beyond the default limit of dynamic LDS
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stream_wave<NI, NBUF>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_stream_wave<NI, NBUF>), dim3(blocks + (uint32_t)q.B), dim3(64), lds, stm, p, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t stm, const NmsParams *fused)
+{
+    if (fused && !(mode == kModeDetect && p.wave_ni)) return hipErrorInvalidValue;
     if (mode == kModeFull) {
         for (int s = 0; s < p.S; ++s) {
             const dim3 grid((p.sc[s].span + kThreads - 1) / kThreads, (uint32_t)p.B);
@@ -457,21 +488,23 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
         }
         return hipSuccess;
     }
-    if (blocks == 0) return hipSuccess;
-    const dim3 grid(blocks), block(kThreads);
     if (mode == kModeDetect && p.wave_ni) {
-        const dim3 wblock(64);
-        const int key = p.wave_ni * 10 + p.wave_nbuf;
-        switch (key) {
-        case 42: hipLaunchKernelGGL((k_stream_wave<4, 2>), grid, wblock, 0, stm, p); break;
-        case 43: hipLaunchKernelGGL((k_stream_wave<4, 3>), grid, wblock, 0, stm, p); break;
-        case 44: hipLaunchKernelGGL((k_stream_wave<4, 4>), grid, wblock, 0, stm, p); break;
-        case 82: hipLaunchKernelGGL((k_stream_wave<8, 2>), grid, wblock, 0, stm, p); break;
-        case 83: hipLaunchKernelGGL((k_stream_wave<8, 3>), grid, wblock, 0, stm, p); break;
+        NmsParams none;
+        std::memset(&none, 0, sizeof(none));
+        const NmsParams &q = fused ? *fused : none;
+        if (blocks == 0 && q.B == 0) return hipSuccess;
+        switch (p.wave_ni * 10 + p.wave_nbuf) {
+        case 42: return launch_wave<4, 2>(p, blocks, stm, q);
+        case 43: return launch_wave<4, 3>(p, blocks, stm, q);
+        case 44: return launch_wave<4, 4>(p, blocks, stm, q);
+        case 82: return launch_wave<8, 2>(p, blocks, stm, q);
+        case 83: return launch_wave<8, 3>(p, blocks, stm, q);
         default: return hipErrorInvalidValue;
         }
     }
-    else if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
+    if (blocks == 0) return hipSuccess;
+    const dim3 grid(blocks), block(kThreads);
+    if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
     else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, 0, stm, p);
     return hipGetLastError();
 }

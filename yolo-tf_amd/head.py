@@ -151,7 +151,7 @@ class DetectionHead:
         return boxes, conf
 
     # ------------------------------------------------------------- detect
-    SMALL_CAPACITY = 2048      # largest capacity of the single-launch candidates -> detections stage
+    SMALL_CAPACITY = 512       # default capacity: the single-launch stage (<= 2048) with a small LDS footprint
 
     def default_max_candidates(self, N):
         """Per-image candidate capacity used when the caller gives none: the
@@ -172,43 +172,57 @@ class DetectionHead:
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         return count, scores, boxes, cls, idx, cc, status
 
+    def _detect_plan(self, heads, cap, max_boxes, slot=0):
+        """(cfg, B, N, workspace) for these head shapes and bounds, planned once;
+        `slot` distinguishes workspaces of batches that are in flight together."""
+        dev = heads[0].device
+        key = ('detect', tuple(tuple(h.shape) for h in heads), cap, int(max_boxes), dev, slot)
+        plan = self._plans.get(key)
+        if plan is None:
+            lib = _abi.load()
+            cfg = self.config_for(heads)
+            B, N = heads[0].shape[0], self.boxes_per_image(heads)
+            nbytes = ctypes.c_size_t(0)
+            _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
+            ws = self._workspace(('detect', B, N, cap, int(max_boxes), slot), nbytes.value, dev)
+            plan = self._plans[key] = (cfg, B, N, ws)
+        return plan
+
+    @staticmethod
+    def _output_pointers(outputs):
+        count, scores, boxes, cls, idx, cc, status = outputs
+        return [count.data_ptr(), scores.data_ptr(), boxes.data_ptr(), cls.data_ptr(), idx.data_ptr(),
+                cc.data_ptr() if cc is not None else None, status.data_ptr()]
+
     def detect(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-               want_class_candidates=False, outputs=None, stream_events=None, _auto=False):
+               want_class_candidates=False, outputs=None, stream_events=None, _auto=False, stream=None):
         """Decode + score filter + per-class NMS for every image (YOLOv3.py:320-368).
-        Enqueues on the current stream and returns device tensors; nothing
-        synchronises until the result is read.  outputs: a tuple from
-        _alloc_outputs to write into (reused across calls by the caller)."""
+        Enqueues on `stream` (a torch.cuda.Stream; default: the current stream)
+        and returns device tensors; nothing synchronises until the result is
+        read.  outputs: a tuple from _alloc_outputs to write into (reused across
+        calls by the caller).  One head object owns one workspace per shape:
+        calls that may overlap on the device (different streams) need different
+        DetectionHead objects.
+        stream_events: a pair of torch.cuda.Event (timing enabled, recorded once
+        before) bracketing the streaming kernel."""
         lib = _abi.load()
         heads = self._check_heads(heads)
         dev = heads[0].device
-        # geometry, capacity and workspace depend only on the shapes: planned once per shape
         N = self.boxes_per_image(heads)
         cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
-        key = ('detect', tuple(tuple(h.shape) for h in heads), cap, int(max_boxes), dev)
-        plan = self._plans.get(key)
-        if plan is None:
-            cfg = self.config_for(heads)
-            B = heads[0].shape[0]
-            nbytes = ctypes.c_size_t(0)
-            _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, int(max_boxes), ctypes.byref(nbytes)))
-            ws = self._workspace(('detect', B, N, cap, int(max_boxes)), nbytes.value, dev)
-            plan = self._plans[key] = (cfg, B, N, cap, ws)
-        cfg, B, N, cap, ws = plan
+        cfg, B, N, ws = self._detect_plan(heads, cap, max_boxes)
         if outputs is None:
             outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
-        count, scores, boxes, cls, idx, cc, status = outputs
         args = [ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
                 float(score_threshold), float(iou_threshold), int(max_boxes), cap,
-                ws.data_ptr(), ws.numel(), count.data_ptr(), scores.data_ptr(),
-                boxes.data_ptr(), cls.data_ptr(), idx.data_ptr(),
-                cc.data_ptr() if cc is not None else None, status.data_ptr(), self._stream(dev)]
+                ws.data_ptr(), ws.numel()] + self._output_pointers(outputs) + [
+                self._stream(dev) if stream is None else ctypes.c_void_p(stream.cuda_stream)]
         with torch.cuda.device(dev):
             if stream_events is None:
                 _abi.check(lib.yh_detect(*args))
             else:
-                # (begin, end): raw hipEvent_t handles recorded around the streaming kernel
-                _abi.check(lib.yh_detect_timed(*args, ctypes.c_void_p(stream_events[0]),
-                                               ctypes.c_void_p(stream_events[1])))
+                _abi.check(lib.yh_detect_timed(*args, ctypes.c_void_p(stream_events[0].cuda_event),
+                                               ctypes.c_void_p(stream_events[1].cuda_event)))
         full = N * self.num_classes
         rerun = None
         if cap < full:
@@ -219,8 +233,8 @@ class DetectionHead:
                 if auto:                                    # remembered for later calls on this geometry
                     self._grown[N] = max(grown, self._grown.get(N, 0))
                 return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown,
-                                   want_class_candidates, _auto=auto)
-        return Detections(count, scores, boxes, cls, idx, cc, status, rerun)
+                                   want_class_candidates, _auto=auto, stream=stream)
+        return Detections(*outputs, rerun)
 
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
             want_class_candidates=False, _auto=False):
@@ -291,3 +305,73 @@ class DetectionHead:
                                    iou.data_ptr() if want_iou_max else None, total.data_ptr(),
                                    self._stream(dev)))
         return dict(per_image=per, sum=total, parts=parts, iou_max=iou)
+
+
+
+class DetectPipeline:
+    """DetectionHead.detect software-pipelined over a sequence of equally shaped
+    batches on one stream (yh_detect_pipelined): submit(heads) streams this
+    batch and, inside the same kernel launch, selects the previous one, whose
+    short latency-bound NMS stage hides behind the bandwidth-bound streaming
+    pass.  submit returns the PREVIOUS batch's Detections (None on the first
+    call); flush() returns the last batch's.  Two workspaces and two output
+    sets alternate: a returned Detections object stays valid until the
+    second submit after it.  Results per batch are those of detect(); a batch
+    whose candidate capacity overflowed is flagged (Detections.overflowed) and
+    has to be submitted again to a pipeline with a larger max_candidates."""
+
+    def __init__(self, head, score_threshold, iou_threshold, max_boxes, max_candidates=None,
+                 want_class_candidates=False, stream=None):
+        self.head = head
+        self.thr, self.iou, self.max_boxes = float(score_threshold), float(iou_threshold), int(max_boxes)
+        self.cap = max_candidates
+        self.want_cc = want_class_candidates
+        self.stream = stream
+        self._i = 0
+        self._prev = None          # (cfg, B, workspace, outputs, device) of the batch awaiting its select stage
+        self._outputs = [None, None]
+
+    def _args(self, cfg, head_ptrs, B, cap, ws, prev_ws, nbytes, outputs, dev, events):
+        ev = events or (None, None)
+        st = self.head._stream(dev) if self.stream is None else ctypes.c_void_p(self.stream.cuda_stream)
+        outs = self.head._output_pointers(outputs) if outputs is not None else [None] * 7
+        return [ctypes.byref(cfg), head_ptrs, B, self.thr, self.iou, self.max_boxes, cap,
+                ws, prev_ws, nbytes] + outs + [
+                st, ctypes.c_void_p(ev[0].cuda_event) if ev[0] is not None else None,
+                ctypes.c_void_p(ev[1].cuda_event) if ev[1] is not None else None]
+
+    def submit(self, heads, stream_events=None):
+        lib = _abi.load()
+        hd = self.head
+        heads = hd._check_heads(heads)
+        dev = heads[0].device
+        N = hd.boxes_per_image(heads)
+        cap = int(self.cap) if self.cap is not None else hd.default_max_candidates(N)
+        slot = self._i & 1
+        cfg, B, N, ws = hd._detect_plan(heads, cap, self.max_boxes, slot=('pipe', slot))
+        prev = self._prev
+        if prev is not None and (prev[1] != B or prev[5] != cap or bytes(prev[0]) != bytes(cfg)):
+            raise ValueError('a pipeline takes equally shaped batches; flush() before changing shape')
+        if self._outputs[slot] is None or self._outputs[slot][0].shape[0] != B:
+            self._outputs[slot] = hd._alloc_outputs(B, self.max_boxes, dev, self.want_cc)
+        args = self._args(cfg, _abi.pointer_array([h.data_ptr() for h in heads]), B, cap, ws.data_ptr(),
+                          prev[2].data_ptr() if prev is not None else None, ws.numel(),
+                          prev[3] if prev is not None else None, dev, stream_events)
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_detect_pipelined(*args))
+        done = Detections(*prev[3], None) if prev is not None else None
+        self._prev = (cfg, B, ws, self._outputs[slot], dev, cap)
+        self._i += 1
+        return done
+
+    def flush(self):
+        prev = self._prev
+        if prev is None:
+            return None
+        lib = _abi.load()
+        cfg, B, ws, outputs, dev, cap = prev
+        args = self._args(cfg, None, B, cap, None, ws.data_ptr(), ws.numel(), outputs, dev, None)
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_detect_pipelined(*args))
+        self._prev = None
+        return Detections(*outputs, None)

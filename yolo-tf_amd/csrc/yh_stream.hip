@@ -230,6 +230,16 @@ __device__ __forceinline__ void lds_peek5(uint32_t addr, float &a, float &b, flo
                  : "memory");
 }
 
+// A staged candidate into LDS.  Also assembly: a ds_write the compiler can see is
+// ordered behind the outstanding LDS-DMA loads just like a read.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_poke_candidate(uint32_t key_addr, uint32_t box_addr, unsigned long long key, float4 box)
+{
+    v4f_t b;
+    b.x = box.x; b.y = box.y; b.z = box.z; b.w = box.w;
+    asm volatile("ds_write_b64 %0, %2\n\tds_write_b128 %1, %3" ::"v"(key_addr), "v"(box_addr), "v"(key), "v"(b) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -422,8 +432,9 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
                     }
                     if (hit) {
                         const int pos = count + __builtin_popcountll(hm & lanes_below);
-                        s_keys[pos] = make_key(c, cf, n);
-                        s_box[pos] = box;
+                        lds_poke_candidate((uint32_t)(uintptr_t)(lds_float_t *)(void *)(s_keys + pos),
+                                           (uint32_t)(uintptr_t)(lds_float_t *)(void *)(s_box + pos),
+                                           make_key(c, cf, n), box);
                     }
                     count += __builtin_popcountll(hm);
                     if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);

@@ -158,11 +158,13 @@ long env_knob(const char *name, long fallback)
     return v > 0 ? v : fallback;
 }
 
-uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode)
+uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t max_candidates = 0)
 {
-    // The detection pass runs wave-private tiles of 4 or 8 KiB when a row fits one.
+    // The detection pass runs wave-private tiles of 4 or 8 KiB when a row fits one.  A capacity
+    // beyond the single-launch select stage announces a dense candidate set (low thresholds): there
+    // the workgroup-tile variant, which appends 512 candidates per atomic, is the faster one.
     p.wave_ni = 0;
-    if (mode == yh::kModeDetect) {
+    if (mode == yh::kModeDetect && max_candidates <= yh::kPostCap) {
         const long ni = env_knob("YH_STREAM_NI", 8);             // tuning knob: 4, 8, anything else = workgroup tiles
         if ((ni == 4 || ni == 8) && (256 * ni - 3) / p.K >= 1) p.wave_ni = (int32_t)ni;
         else if (ni == 4 && (256 * 8 - 3) / p.K >= 1) p.wave_ni = 8;
@@ -310,7 +312,7 @@ int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t 
         return fail(YH_ERR_INVALID_ARG, "bad batch / max_candidates / nms_max_boxes");
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, nullptr, batch);
-    if (batch > 0) plan_stream(p, batch, yh::kModeDetect);
+    if (batch > 0) plan_stream(p, batch, yh::kModeDetect, max_candidates);
     *bytes = carve_detect(nullptr, batch, boxes_per_image(cfg), cfg->num_classes, max_candidates,
                           nms_max_boxes, true, p.upi).bytes;
     return YH_OK;
@@ -392,7 +394,7 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
     const int64_t N = boxes_per_image(cfg);
     yh::StreamParams &p = d.p;
     fill_stream_from_config(p, cfg, want_stream ? heads : nullptr, batch);
-    d.blocks = plan_stream(p, batch, yh::kModeDetect);
+    d.blocks = plan_stream(p, batch, yh::kModeDetect, max_candidates);
     const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true, p.upi);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);

@@ -345,6 +345,27 @@ def test_loss_v3_matches_oracle(gpu, c_oracle, G, B):
     assert_close(out['per_image'][0].item(), n0, what='loss vs numpy')
 
 
+@pytest.mark.parametrize('thr', [0.0, 0.3, 0.5, 0.9, 1.0])
+def test_loss_mask_decided_without_division_is_the_same_mask(gpu, thr):
+    """Without iou_max the ignore mask is decided by a margin test with the division as a
+    fallback: the no-object sums (same summation order) must be the very same bits."""
+    case = cases.v3()
+    heads = to_dev(case.heads(91, 3), gpu)
+    gt = case.gt(92, 3, 60, 64)
+    gt[0, :5, 2:4] = 0.0                                     # zero-area boxes
+    gt[1, 0, :4] = (1e30, 1e30, 1e30, 1e30)                  # products overflow: non-finite IoU
+    dgt = torch.from_numpy(gt).to(gpu)
+    hd = case.head_obj()
+    exact = hd.loss(heads, dgt, 1., 1., 5., 1., thr, True, want_parts=True, want_iou_max=True)
+    fast = hd.loss(heads, dgt, 1., 1., 5., 1., thr, True, want_parts=True)
+    a, b = exact['parts'].cpu().numpy(), fast['parts'].cpu().numpy()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(exact['per_image'].cpu().numpy().view(np.uint32), fast['per_image'].cpu().numpy().view(np.uint32))
+    # the mask is not trivial at this threshold
+    m = exact['iou_max'].cpu().numpy()
+    assert 0 < np.count_nonzero(m > thr) or thr >= 0.9
+
+
 def test_loss_v2_matches_oracle(gpu, c_oracle):
     case = cases.v2(size=480)
     B, G = 4, 9

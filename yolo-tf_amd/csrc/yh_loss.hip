@@ -47,20 +47,27 @@ __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx
 }
 
 // ---------------------------------------------------------------- negative
-// grid = B * blocks_per_img; a block owns 256 consecutive box rows of one scale
-// of one image.  Dynamic LDS: 5 * pad floats (GT corners + area at this scale)
+// B * blocks_per_img workgroups; one owns 256 consecutive box rows of one scale
+// of one image.  s_raw: 5 * pad floats (GT corners + area at this scale)
 // followed by the cell-occupancy bitmap of the scale.
-__global__ __launch_bounds__(kLossNegThreads) void k_loss_neg(const LossParams p)
+//
+// EXACT_MAX = false (the caller does not ask for the IoU maxima): only the
+// predicate "some IoU exceeds the threshold" is needed, and it is decided
+// without the division wherever that is safe: RN(inter / union) > thr follows from
+// sign(union) * inter > thr * |union| by a margin far wider than the roundings
+// involved, and its negation likewise; a box with a pair inside the margin, or
+// with a zero or non-finite union, is walked again with the division.  Same
+// decisions, less arithmetic.
+template <bool EXACT_MAX>
+__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw,
+                                               float *s_val, int *s_idx)
 {
-    extern __shared__ __align__(16) unsigned char s_raw[];
-    __shared__ float s_val[kLossNegThreads / 64];
-    __shared__ int s_idx[kLossNegThreads / 64];
     float *s_gt = reinterpret_cast<float *>(s_raw);                 // [pad][5]: y1 x1 y2 x2 area
     uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_raw + (size_t)p.pad * 5 * sizeof(float));
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / p.blocks_per_img;
-    const uint32_t r = blockIdx.x - (uint32_t)b * p.blocks_per_img;
+    const int b = block / p.blocks_per_img;
+    const uint32_t r = block - (uint32_t)b * p.blocks_per_img;
     int s = 0;
 #pragma unroll
     for (int i = 1; i < YH_MAX_SCALES; ++i)
@@ -112,22 +119,56 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_neg(const LossParams p
             const float by1 = ly - uy / 2.0f, bx1 = lx - ux / 2.0f;
             const float by2 = ly + uy / 2.0f, bx2 = lx + ux / 2.0f;
             const float aarea = (by2 - by1) * (bx2 - bx1);
-            m = -INFINITY;
-            bool any_nan = false;
-            for (int g = 0; g < G; ++g) {
-                const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
-                const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
-                const float garea = s_gt[g * 5 + 4];
-                // intersection NOT clamped at zero (YOLOv3.py:286)
-                const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
-                const float iou = inter / ((aarea + garea) - inter);
-                if (iou != iou) any_nan = true;
-                else if (iou > m) m = iou;
+            if (EXACT_MAX) {
+                m = -INFINITY;
+                bool any_nan = false;
+                for (int g = 0; g < G; ++g) {
+                    const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
+                    const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
+                    const float garea = s_gt[g * 5 + 4];
+                    // intersection NOT clamped at zero (YOLOv3.py:286)
+                    const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                    const float iou = inter / ((aarea + garea) - inter);
+                    if (iou != iou) any_nan = true;
+                    else if (iou > m) m = iou;
+                }
+                if (any_nan) m = __builtin_nanf("");
+                if (m <= p.ignore_thr) contrib = sigmoid_ce(obj, 0.0f);
+            } else {
+                // Branch-free pass: sign(uni) * inter against thr * |uni| with a relative margin of
+                // 2^-20 on either side (the roundings involved are below 2^-23).  Pairs inside the
+                // margin, or with a zero, tiny or non-finite union, raise `recheck`.
+                const float thr = p.ignore_thr;
+                const float thr_hi = thr * (1.0f + 0x1p-20f), thr_lo = thr * (1.0f - 0x1p-20f);
+                int masked = 0, recheck = thr >= 0.0f ? 0 : 1;
+                for (int g = 0; g < G; ++g) {
+                    const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
+                    const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
+                    const float garea = s_gt[g * 5 + 4];
+                    const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                    const float uni = (aarea + garea) - inter;
+                    const float au = fabsf(uni);
+                    const float si = __uint_as_float(__float_as_uint(inter) ^ (__float_as_uint(uni) & 0x80000000u));
+                    const int valid = (au >= 0x1p-100f) & (au <= 3.4028235e38f);
+                    const int gt = si > thr_hi * au, le = si < thr_lo * au;
+                    masked |= valid & gt;
+                    recheck |= (valid & (gt | le)) ^ 1;
+                }
+                if (recheck) {                    // rare: the exact walk decides
+                    masked = 0;
+                    for (int g = 0; g < G; ++g) {
+                        const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
+                        const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
+                        const float garea = s_gt[g * 5 + 4];
+                        const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                        const float iou = inter / ((aarea + garea) - inter);
+                        masked |= (iou != iou) | (iou > thr);
+                    }
+                }
+                if (!masked) contrib = sigmoid_ce(obj, 0.0f);
             }
-            if (any_nan) m = __builtin_nanf("");
-            if (m <= p.ignore_thr) contrib = sigmoid_ce(obj, 0.0f);
         }
-        if (p.iou_max) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
+        if (EXACT_MAX) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
     }
 
     // block sum, fixed order
@@ -143,17 +184,15 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_neg(const LossParams p
 }
 
 // ---------------------------------------------------------------- positive
-// grid = B * pos_blocks; one wavefront per ground-truth row.  Every lane
+// B * pos_blocks workgroups; one wavefront per ground-truth row.  Every lane
 // evaluates the (cheap) assignment redundantly, then the lanes split the K
 // channels of the assigned head row.
-__global__ __launch_bounds__(kPosThreads) void k_loss_pos(const LossParams p)
+__device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t block, float *s_val, int *s_idx,
+                                               float (*s_part)[3])
 {
-    __shared__ float s_val[kPosThreads / 64];
-    __shared__ int s_idx[kPosThreads / 64];
-    __shared__ float s_part[kPosThreads / 64][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.pos_blocks;
-    const int blk = blockIdx.x - b * p.pos_blocks;
+    const int b = (int)(block / (uint32_t)p.pos_blocks);
+    const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
     const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
     if (blk == 0 && tid == 0) p.gcount[b] = G;
@@ -245,20 +284,47 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_pos(const LossParams p)
     }
 }
 
+// One launch for both branches: the last B * pos_blocks workgroups take the
+// positive branch (short, latency-bound: they fill in behind the negative ones).
+static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
+template <bool EXACT_MAX>
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
+{
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ float s_val[kLossNegThreads / 64];
+    __shared__ int s_idx[kLossNegThreads / 64];
+    __shared__ float s_part[kLossNegThreads / 64][3];
+    const uint32_t nneg = (uint32_t)p.B * (uint32_t)p.blocks_per_img;
+    if (blockIdx.x < nneg) loss_neg_block<EXACT_MAX>(p, blockIdx.x, s_raw, s_val, s_idx);
+    else loss_pos_block(p, blockIdx.x - nneg, s_val, s_idx, s_part);
+}
+
 // ---------------------------------------------------------------- finalize
 // One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
-// the batch sum in a fixed order.
-__global__ __launch_bounds__(256) void k_loss_finalize(const LossParams p)
+// the batch sum.  A wavefront per image: the lanes fetch the image's partial sums
+// together and add them up in double in a fixed tree, so the result does not
+// depend on scheduling.
+constexpr int kFinalizeThreads = 1024;
+
+__device__ __forceinline__ double wave_sum(double v)
 {
-    __shared__ double s_sum[256];
-    const int tid = threadIdx.x;
-    double local = 0.0;
-    for (int b = tid; b < p.B; b += 256) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
+{
+    __shared__ double s_sum[kFinalizeThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double local = 0.0;                                        // lane 0 of each wave: its images' losses
+    for (int b = wave; b < p.B; b += kFinalizeThreads / 64) {
         double coord = 0.0, cls = 0.0, obj = 0.0, noobj = 0.0;
         const float *pp = p.pos_partial + (long long)b * p.pos_blocks * 3;
-        for (int i = 0; i < p.pos_blocks; ++i) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
+        for (int i = lane; i < p.pos_blocks; i += 64) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
         const float *np_ = p.neg_partial + (long long)b * p.blocks_per_img;
-        for (int i = 0; i < p.blocks_per_img; ++i) noobj += np_[i];
+        for (int i = lane; i < p.blocks_per_img; i += 64) noobj += np_[i];
+        coord = wave_sum(coord); cls = wave_sum(cls); obj = wave_sum(obj); noobj = wave_sum(noobj);
         const float fc = (float)coord, fk = (float)cls, fo = (float)obj, fn = (float)noobj;
         float pos = (p.w_coord * fc + p.w_class * fk) + p.w_obj * fo;
         float neg = p.w_noobj * fn;
@@ -267,20 +333,22 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const LossParams p)
             pos = pos / gf; neg = neg / gf;
         }
         const float li = pos + neg;
-        p.loss_per_image[b] = li;
-        if (p.loss_parts) {
-            p.loss_parts[b * 4 + 0] = fc; p.loss_parts[b * 4 + 1] = fk;
-            p.loss_parts[b * 4 + 2] = fo; p.loss_parts[b * 4 + 3] = fn;
+        if (lane == 0) {
+            p.loss_per_image[b] = li;
+            if (p.loss_parts) {
+                p.loss_parts[b * 4 + 0] = fc; p.loss_parts[b * 4 + 1] = fk;
+                p.loss_parts[b * 4 + 2] = fo; p.loss_parts[b * 4 + 3] = fn;
+            }
+            local += (double)li;
         }
-        local += (double)li;
     }
-    s_sum[tid] = local;
+    if (lane == 0) s_sum[wave] = local;
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if (tid < d) s_sum[tid] += s_sum[tid + d];
-        __syncthreads();
+    if (tid == 0 && p.loss_sum) {
+        double acc = 0.0;
+        for (int w = 0; w < kFinalizeThreads / 64; ++w) acc += s_sum[w];
+        *p.loss_sum = (float)acc;
     }
-    if (tid == 0 && p.loss_sum) *p.loss_sum = (float)s_sum[0];
 }
 
 hipError_t launch_loss(const LossParams &p, hipStream_t stm)
@@ -292,13 +360,12 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         if (w > occ_words) occ_words = w;
     }
     const size_t lds = (size_t)p.pad * 5 * sizeof(float) + (size_t)occ_words * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_loss_pos, dim3((uint32_t)p.B * p.pos_blocks), dim3(kPosThreads), 0, stm, p);
-    hipError_t e = hipGetLastError();
+    const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
+    if (p.iou_max) hipLaunchKernelGGL(k_loss_main<true>, grid, dim3(kLossNegThreads), lds, stm, p);
+    else hipLaunchKernelGGL(k_loss_main<false>, grid, dim3(kLossNegThreads), lds, stm, p);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_loss_neg, dim3((uint32_t)p.B * p.blocks_per_img), dim3(kLossNegThreads), lds, stm, p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, stm, p);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kFinalizeThreads), 0, stm, p);
     return hipGetLastError();
 }
 

@@ -39,9 +39,10 @@ def global_mean_loss(local_sum, local_batch):
     """reduce_mean over the global batch.  local_sum: tensor [1] (or 0-dim)
     holding this rank's sum of per-image losses.  Returns a 0-dim float32
     tensor on local_sum's device, identical on every rank."""
-    s = local_sum.reshape(()).to(torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        buf = torch.stack([s, torch.tensor(float(local_batch), dtype=torch.float64, device=s.device)])
+        buf = torch.empty(2, dtype=torch.float64, device=local_sum.device)
+        buf[0] = local_sum.reshape(())
+        buf[1] = float(local_batch)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return (buf[0] / buf[1]).to(torch.float32)
-    return (s / float(local_batch)).to(torch.float32)
+    return local_sum.reshape(()) / float(local_batch)          # one rank: the fp32 mean the reference computes

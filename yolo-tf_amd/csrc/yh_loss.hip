@@ -15,6 +15,22 @@ namespace yh {
 
 constexpr int kPosThreads = 64 * kLossPosGtPerBlock;
 
+// fminf / fmaxf as the bare instructions (IEEE mode: a NaN operand yields the other one, as
+// fminf / fmaxf do).  The compiler's own expansion first canonicalises operands it loaded from
+// memory, one extra instruction per operand, in the innermost loop of the negative branch.
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // _get_normlized_gn's slice (YOLOv3.py:437): the first index of the minimum of
 // column 0 of gt [pad][5].  Block-wide; result broadcast through *out.
 __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx, int nthreads)
@@ -127,7 +143,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                     const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
                     const float garea = s_gt[g * 5 + 4];
                     // intersection NOT clamped at zero (YOLOv3.py:286)
-                    const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                    const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
                     const float iou = inter / ((aarea + garea) - inter);
                     if (iou != iou) any_nan = true;
                     else if (iou > m) m = iou;
@@ -145,7 +161,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                     const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
                     const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
                     const float garea = s_gt[g * 5 + 4];
-                    const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                    const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
                     const float uni = (aarea + garea) - inter;
                     const float au = fabsf(uni);
                     const float si = __uint_as_float(__float_as_uint(inter) ^ (__float_as_uint(uni) & 0x80000000u));
@@ -160,7 +176,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                         const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
                         const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
                         const float garea = s_gt[g * 5 + 4];
-                        const float inter = (fminf(gy2, by2) - fmaxf(gy1, by1)) * (fminf(gx2, bx2) - fmaxf(gx1, bx1));
+                        const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
                         const float iou = inter / ((aarea + garea) - inter);
                         masked |= (iou != iou) | (iou > thr);
                     }

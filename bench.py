@@ -249,7 +249,7 @@ def main():
             ach = value / world * bytes_img / 1e9
             res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
-                                   kernel='whole loss step (k_loss_pos + k_loss_neg + k_loss_finalize), wall clock',
+                                   kernel='whole loss step (k_loss_main + k_loss_finalize + the scalar mean), wall clock',
                                    algorithmic_bytes_per_launch=B * bytes_img)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(w, grids, priors, box_mult, gt_rate)

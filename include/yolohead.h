@@ -210,6 +210,34 @@ int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *g
             float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
             void *stream);
 
+/* The loss with its backward: what `optimizer.minimize(loss)` differentiates at
+ * YOLOv3.py:312-318 / YOLOv2.py:175-181, up to the head tensors (the network
+ * behind them is outside this path).
+ *   yh_loss_forward  = yh_loss, and records in noobj_mask [B][N] (uint8) which
+ *                      boxes entered the no-object sum (cell without a GT centre
+ *                      and IoU maximum <= ignore_threshold; YOLOv3.py:298-307);
+ *   yh_loss_backward   writes d(sum_b grad_per_image[b] * loss_per_image[b]) /
+ *                      d(head) into grad_heads (host array of num_scales device
+ *                      pointers, shaped like heads, completely overwritten; must
+ *                      not alias heads).  heads, ground_truth, loss_scales,
+ *                      normalize_by_num_gt and noobj_mask are those of the
+ *                      forward call.  The ignore mask and the target assignment
+ *                      are piecewise constant in the head, as in the reference's
+ *                      graph (they depend on priors and ground truth only), so
+ *                      the gradient is closed-form: w * (sigmoid(x) - target)
+ *                      for the cross-entropy terms, w * (t - log(g / prior)) for
+ *                      the size terms, divided by the GT count when
+ *                      normalize_by_num_gt is set. */
+int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                    int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                    int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                    float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                    uint8_t *noobj_mask, void *stream);
+int yh_loss_backward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                     int32_t batch, int32_t pad, const float *loss_scales, int32_t normalize_by_num_gt,
+                     const uint8_t *noobj_mask, const float *grad_per_image, float *const *grad_heads,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

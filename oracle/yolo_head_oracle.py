@@ -411,3 +411,72 @@ def noobj_iou_max(heads_i, ground_truth_i, priors, gt_rate, num_classes):
         _, full = _scale_noobj(sp, 0.5, return_iou=True)
         out.append(full.reshape(-1))
     return np.concatenate(out).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# gradient of the loss w.r.t. the head tensors
+# --------------------------------------------------------------------------
+
+def _loss_grad_scales(heads_i, gn, sp, masks, priors, num_classes, weights, inv_g, ignore_threshold):
+    """Closed-form d(loss_i)/d(head) for one image, the derivative TF's autodiff takes
+    of YOLOv3.py:190-310 / YOLOv2.py:128-172 (optimizer.minimize, YOLOv3.py:312-318):
+    the GT selection, the best-prior index and the ignore mask do not depend on the
+    head, so only the cross-entropy and squared-error terms differentiate:
+    d CE(x, z)/dx = sigmoid(x) - z, d 0.5 (t - u)^2/dt = t - u.  float64 arithmetic on
+    the fp32 inputs.  Returns one [H, W, P*(C+5)] float64 array per scale."""
+    C = num_classes
+    K = C + 5
+    w_coord, w_noobj, w_obj, w_class = [float(w) for w in weights]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+    grads = []
+    for s, h in enumerate(heads_i):
+        pr = np.asarray(priors[s], F32)
+        P = pr.shape[0]
+        H, W = h.shape[0], h.shape[1]
+        hv = np.asarray(h, np.float64).reshape(H, W, P, K)
+        g = np.zeros((H, W, P, K), np.float64)
+        # no-object term (YOLOv3.py:242-307): boxes outside GT cells whose IoU maximum <= threshold
+        _, full = _scale_noobj(sp[s], ignore_threshold, return_iou=True)
+        with np.errstate(invalid='ignore'):
+            wmask = (full <= F32(ignore_threshold)).reshape(H, W, P)
+        g[..., C + 4] = np.where(wmask, w_noobj * inv_g * sig(hv[..., C + 4]), 0.0)
+        # assigned rows (YOLOv3.py:190-241)
+        g_yx, g_hw, g_label = gn[s]
+        for j in np.nonzero(masks[s])[0]:
+            cy, cx = int(np.floor(g_yx[j, 0])), int(np.floor(g_yx[j, 1]))
+            p = int(sp[s]['index'][j])
+            v = hv[cy, cx, p]
+            d = np.zeros((K,), np.float64)
+            onehot = np.zeros((C,), np.float64); onehot[int(g_label[j])] = 1.0
+            d[:C] = w_class * (sig(v[:C]) - onehot)
+            frac = (g_yx[j] - np.floor(g_yx[j])).astype(F32).astype(np.float64)
+            d[C:C + 2] = w_coord * (sig(v[C:C + 2]) - frac)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                target = np.log((g_hw[j] / pr[p]).astype(F32)).astype(np.float64)
+            d[C + 2:C + 4] = w_coord * (v[C + 2:C + 4] - target)
+            d[C + 4] = w_obj * (sig(v[C + 4]) - 1.0)
+            g[cy, cx, p] += d * inv_g                         # several GT rows may share a box
+        grads.append(g.reshape(H, W, P * K))
+    return grads
+
+
+def loss_v3_grad_image(heads_i, ground_truth_i, priors, num_classes,
+                       coord_scale=1., noobj_scale=1., obj_scale=5., class_scale=1.):
+    """d loss_v3_image / d heads_i."""
+    _, parts = loss_v3_image(heads_i, ground_truth_i, priors, num_classes, coord_scale, noobj_scale,
+                             obj_scale, class_scale, return_parts=True)
+    gn = [normalized_gn(ground_truth_i, V3_GT_RATE[s]) for s in range(3)]
+    sp = [_scale_positive_part(heads_i[s], priors[s], gn[s][0], gn[s][1], num_classes) for s in range(3)]
+    inv_g = 1.0 / float(parts['num_g'])
+    return _loss_grad_scales(heads_i, gn, sp, parts['masks'], priors, num_classes,
+                             (coord_scale, noobj_scale, obj_scale, class_scale), inv_g, 0.5)
+
+
+def loss_v2_grad_image(head_i, ground_truth_i, priors, num_classes,
+                       coord_scale=1., noobj_scale=1., obj_scale=5., class_scale=1.):
+    """d loss_v2_image / d head_i (one scale, every GT assigned, no division by the GT count)."""
+    gn = [normalized_gn(ground_truth_i, V2_GT_RATE[0])]
+    sp = [_scale_positive_part(head_i, priors, gn[0][0], gn[0][1], num_classes)]
+    masks = [np.ones((gn[0][2].shape[0],), dtype=bool)]
+    return _loss_grad_scales([head_i], gn, sp, masks, [priors], num_classes,
+                             (coord_scale, noobj_scale, obj_scale, class_scale), 1.0, 0.6)[0]

@@ -366,6 +366,58 @@ def test_loss_mask_decided_without_division_is_the_same_mask(gpu, thr):
     assert 0 < np.count_nonzero(m > thr) or thr >= 0.9
 
 
+@pytest.mark.parametrize('version,B,G', [(3, 3, 40), (3, 2, 1), (2, 4, 12)])
+def test_loss_backward_matches_oracle(gpu, version, B, G):
+    """Gradient w.r.t. the head tensors through the autograd Function (yh_loss_forward +
+    yh_loss_backward) against the closed-form NumPy restatement (float64), 1e-5 relative."""
+    case = cases.v3(size=224, C=20) if version == 3 else cases.v2(size=224, C=20)
+    heads = case.heads(95, B, obj_mean=-1.0)
+    gt = case.gt(96, B, G, G + 3)
+    if G > 2:
+        gt[0, 1, :2] = gt[0, 0, :2]                          # two GT rows share a cell
+    dheads = [h.requires_grad_(True) for h in to_dev(heads, gpu)]
+    thr, norm = (0.5, True) if version == 3 else (0.6, False)
+    hd = case.head_obj()
+    total, per = hd.loss_with_grad(dheads, torch.from_numpy(gt).to(gpu), 1., 1., 5., 1., thr, norm)
+    weights = torch.linspace(0.5, 1.5, B, device=gpu)
+    ((total / B).sum() * 0.5 + (per * weights).sum()).backward()    # uses both outputs
+    for b in range(B):
+        hi = [h[b] for h in heads]
+        if version == 3:
+            want = O.loss_v3_grad_image(hi, gt[b], case.priors, case.C)
+        else:
+            want = [O.loss_v2_grad_image(hi[0], gt[b], case.priors[0], case.C)]
+        scale = 0.5 / B + float(weights[b])
+        for s, w in enumerate(want):
+            got = dheads[s].grad[b].cpu().numpy()
+            assert np.count_nonzero(w) > 0
+            assert_close(got, w * scale, rtol=RTOL, atol=1e-7, what='grad image %d scale %d' % (b, s))
+            assert np.array_equal(got == 0, w == 0) or np.count_nonzero((got == 0) != (w == 0)) <= 2
+
+
+def test_loss_backward_is_the_derivative_of_the_forward(gpu):
+    """Directional finite difference of the GPU loss itself (fp32 forward evaluated at
+    +-eps along a random direction) against <grad, direction>: 1e-3, the resolution of
+    an fp32 difference quotient."""
+    case = cases.v3(size=160, C=10)
+    B = 2
+    heads = to_dev(case.heads(97, B, obj_mean=-1.0), gpu)
+    gt = torch.from_numpy(case.gt(98, B, 8, 10)).to(gpu)
+    hd = case.head_obj()
+    hs = [h.clone().requires_grad_(True) for h in heads]
+    total, _ = hd.loss_with_grad(hs, gt, 1., 1., 5., 1., 0.5, True)
+    total.sum().backward()
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    dirs = [torch.randn(h.shape, generator=gen).to(gpu) for h in heads]
+    analytic = sum(float((h.grad.double() * d.double()).sum()) for h, d in zip(hs, dirs))
+    eps = 1e-2
+    def f(sign):
+        out = hd.loss([h + sign * eps * d for h, d in zip(heads, dirs)], gt, 1., 1., 5., 1., 0.5, True)
+        return float(out['per_image'].double().sum())
+    numeric = (f(+1) - f(-1)) / (2 * eps)
+    assert abs(numeric - analytic) <= 1e-3 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
 def test_loss_v2_matches_oracle(gpu, c_oracle):
     case = cases.v2(size=480)
     B, G = 4, 9
@@ -447,6 +499,52 @@ def test_class_api_v3(gpu, c_oracle, capsys):
                                    (1., 1., 5., 1.), 0.5, True)
         wants.append(np.float32(0.5) * m)
     assert_close(mean_loss, np.mean(wants), what='epoch mean loss')
+
+
+def test_train_one_epoch_trains_through_the_fused_loss(gpu, capsys):
+    """A head provider whose outputs carry an autograd graph gets gradients from
+    yh_loss_backward and its step(lr) is called (optimizer.minimize, YOLOv3.py:312-318):
+    the loss of a fixed batch goes down epoch after epoch."""
+    case = cases.v3(size=160, C=5)
+    Bt = 4
+
+    class Provider:                                            # the smallest "network": a learnable bias on fixed features
+        def __init__(self):
+            self.base = to_dev(case.heads(140, Bt, obj_mean=-1.0), gpu)
+            self.bias = [torch.zeros_like(b[:1]).requires_grad_(True) for b in self.base]
+            self.steps = 0
+
+        def __call__(self, images):
+            return [b + w for b, w in zip(self.base, self.bias)]
+
+        def zero_grad(self):
+            for w in self.bias:
+                w.grad = None
+
+        def step(self, lr):
+            with torch.no_grad():
+                for w in self.bias:
+                    w -= lr * w.grad
+            self.steps += 1
+
+    prov = Provider()
+    gt = torch.from_numpy(case.gt(141, Bt, 5, 8)).to(gpu)
+
+    def batches():
+        while True:
+            yield torch.zeros((Bt, 160, 160, 3), device=gpu), gt
+    cfg = dict(mode='train', data_shape=[160, 160, 3], num_classes=5, weight_decay=0.0, keep_prob=0.5,
+               data_format='channels_last', batch_size=Bt, coord_scale=1, noobj_scale=1, obj_scale=5.,
+               class_scale=1., num_priors=3, nms_score_threshold=0.5, nms_max_boxes=10,
+               nms_iou_threshold=0.5, priors=y.synth.V3_PRIORS, head_provider=prov)
+    data = dict(data_shape=[160, 160, 3], num_train=5 * Bt, num_val=0, train_generator=(None, batches()),
+                val_generator=None)
+    net = y.YOLOv3(cfg, data)
+    losses = [float(net.train_one_epoch(0.05)) for _ in range(4)]
+    capsys.readouterr()
+    assert prov.steps == 20
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.99 * losses[0], losses
 
 
 def test_class_api_v2(gpu, c_oracle, capsys):

@@ -157,3 +157,71 @@ def test_v3_quirks():
     np.testing.assert_allclose(bb[0], [(1.0 - (10 / 8. + 1) / 2) * 32, (1.0 - (13 / 8. + 1) / 2) * 32,
                                        (1.0 + (10 / 8. + 1) / 2) * 32, (1.0 + (13 / 8. + 1) / 2) * 32], rtol=1e-6)
     assert np.all(cf == np.float32(0.25))
+
+
+def _torch_loss_image(heads_t, gt_i, case, version, weights=(1., 1., 5., 1.)):
+    """The loss of one image as a differentiable torch float64 expression.  The discrete
+    decisions (GT selection per scale, best prior, ignore mask) come from the NumPy
+    restatement; the expression itself is written with torch's own loss primitives."""
+    import torch
+    import torch.nn.functional as F
+    C, K = case.C, case.C + 5
+    w_coord, w_noobj, w_obj, w_class = weights
+    heads_np = [h.detach().numpy().astype(np.float32) for h in heads_t]
+    S = len(heads_t)
+    rates = O.V3_GT_RATE if version == 3 else O.V2_GT_RATE
+    thr = 0.5 if version == 3 else 0.6
+    gn = [O.normalized_gn(gt_i, rates[s]) for s in range(S)]
+    sp = [O._scale_positive_part(heads_np[s], case.priors[s], gn[s][0], gn[s][1], C) for s in range(S)]
+    if version == 3:
+        _, parts = O.loss_v3_image(heads_np, gt_i, case.priors, C, return_parts=True)
+        masks, num_g = parts['masks'], parts['num_g']
+    else:
+        masks, num_g = [np.ones((gn[0][2].shape[0],), bool)], 1
+    coord = cls = obj = noobj = 0.0
+    for s in range(S):
+        P = case.priors[s].shape[0]
+        H, W = heads_np[s].shape[:2]
+        hv = heads_t[s].reshape(H, W, P, K)
+        _, full = O._scale_noobj(sp[s], thr, return_iou=True)
+        with np.errstate(invalid='ignore'):
+            w = torch.from_numpy((full <= np.float32(thr)).reshape(H, W, P).astype(np.float64))
+        noobj = noobj + (F.softplus(hv[..., C + 4]) * w).sum()          # CE(x, 0) = softplus(x)
+        g_yx, g_hw, g_label = gn[s]
+        for j in np.nonzero(masks[s])[0]:
+            cy, cx, p = int(np.floor(g_yx[j, 0])), int(np.floor(g_yx[j, 1])), int(sp[s]['index'][j])
+            v = hv[cy, cx, p]
+            onehot = torch.zeros(C, dtype=torch.float64); onehot[int(g_label[j])] = 1.0
+            cls = cls + F.binary_cross_entropy_with_logits(v[:C], onehot, reduction='sum')
+            frac = torch.from_numpy((g_yx[j] - np.floor(g_yx[j])).astype(np.float32).astype(np.float64))
+            coord = coord + F.binary_cross_entropy_with_logits(v[C:C + 2], frac, reduction='sum')
+            target = torch.from_numpy(np.log((g_hw[j] / case.priors[s][p]).astype(np.float32)).astype(np.float64))
+            coord = coord + 0.5 * ((v[C + 2:C + 4] - target) ** 2).sum()
+            obj = obj + F.softplus(-v[C + 4])                                # CE(x, 1) = softplus(-x)
+    return ((w_coord * coord + w_class * cls + w_obj * obj) + w_noobj * noobj) / num_g
+
+
+@pytest.mark.parametrize('version', [3, 2])
+def test_gradient_restatement_against_torch_autograd(version):
+    """Pins oracle.loss_v*_grad_image: torch autograd of an independent float64 expression of
+    the same loss (whose value is first checked against the fp32 restatement)."""
+    import torch
+    case = cases.v3(size=160, C=7) if version == 3 else cases.v2(size=160, C=6)
+    heads = case.heads(5, 1, obj_mean=-1.0)
+    gt = case.gt(6, 1, 9, 12)
+    gt[0, 3, :2] = gt[0, 2, :2]                              # two GT rows in one cell
+    heads_i = [h[0] for h in heads]
+    heads_t = [torch.from_numpy(h.astype(np.float64)).requires_grad_(True) for h in heads_i]
+    loss = _torch_loss_image(heads_t, gt[0], case, version)
+    if version == 3:
+        want_loss = O.loss_v3_image(heads_i, gt[0], case.priors, case.C)
+        got = O.loss_v3_grad_image(heads_i, gt[0], case.priors, case.C)
+    else:
+        want_loss = O.loss_v2_image(heads_i[0], gt[0], case.priors[0], case.C)
+        got = [O.loss_v2_grad_image(heads_i[0], gt[0], case.priors[0], case.C)]
+    assert abs(loss.item() - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+    loss.backward()
+    for g, t in zip(got, heads_t):
+        ref = t.grad.numpy()
+        assert np.count_nonzero(ref) > 0
+        assert np.allclose(g, ref, rtol=1e-9, atol=1e-12)

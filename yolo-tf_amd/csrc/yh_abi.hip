@@ -644,11 +644,11 @@ int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pa
     return YH_OK;
 }
 
-int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
-            int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
-            int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
-            float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
-            void *stream)
+int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                    int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                    int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                    float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                    uint8_t *noobj_mask, void *stream)
 {
     int rc = check_config(cfg);
     if (rc != YH_OK) return rc;
@@ -672,8 +672,50 @@ int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *g
     p.gt = ground_truth;
     p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount;
     p.loss_per_image = loss_per_image; p.loss_parts = loss_parts; p.iou_max = iou_max; p.loss_sum = loss_sum;
+    p.noobj_mask = noobj_mask;
     const hipError_t e = yh::launch_loss(p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "loss launch");
+    return YH_OK;
+}
+
+int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+            int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+            int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+            float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+            void *stream)
+{
+    return yh_loss_forward(cfg, heads, ground_truth, batch, pad, loss_scales, ignore_threshold, normalize_by_num_gt,
+                           workspace, workspace_bytes, loss_per_image, loss_parts, iou_max, loss_sum, nullptr, stream);
+}
+
+int yh_loss_backward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                     int32_t batch, int32_t pad, const float *loss_scales, int32_t normalize_by_num_gt,
+                     const uint8_t *noobj_mask, const float *grad_per_image, float *const *grad_heads,
+                     void *stream)
+{
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if ((rc = check_loss_sizes(cfg, batch, pad)) != YH_OK) return rc;
+    if (!loss_scales) return fail(YH_ERR_INVALID_ARG, "loss_scales is null");
+    if (batch == 0) return YH_OK;
+    if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
+    if (!ground_truth || !noobj_mask || !grad_per_image || !grad_heads)
+        return fail(YH_ERR_INVALID_ARG, "null ground_truth, noobj_mask, grad_per_image or grad_heads");
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        if (!grad_heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] is null", s);
+        if (grad_heads[s] == heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] aliases heads[%d]", s, s);
+    }
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    yh::LossParams p;
+    plan_loss(p, cfg, batch, pad);
+    for (int s = 0; s < p.S; ++s) { p.sc[s].head = heads[s]; p.sc[s].grad = grad_heads[s]; }
+    p.w_coord = loss_scales[0]; p.w_noobj = loss_scales[1]; p.w_obj = loss_scales[2]; p.w_class = loss_scales[3];
+    p.normalize = normalize_by_num_gt ? 1 : 0;
+    p.gt = ground_truth;
+    p.noobj_mask = const_cast<uint8_t *>(noobj_mask);
+    p.grad_w = grad_per_image;
+    const hipError_t e = yh::launch_loss_backward(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "loss backward launch");
     return YH_OK;
 }
 

@@ -146,6 +146,7 @@ struct LossScale {
     uint32_t row_base;
     uint32_t blk_begin;     // first negative-branch block of this scale inside an image
     float gt_rate;
+    float *grad;            // backward: d/d(head), same shape as head
     float prior_hw[YH_MAX_PRIORS][2];
 };
 
@@ -164,10 +165,13 @@ struct LossParams {
     float *loss_parts;            // [B][4] or null
     float *iou_max;               // [B][N] or null
     float *loss_sum;              // [1]
+    uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
+    const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
     LossScale sc[YH_MAX_SCALES];
 };
 
 hipError_t launch_loss(const LossParams &p, hipStream_t st);
+hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;
 constexpr int kLossPosGtPerBlock = 4;   // one wave per ground-truth box

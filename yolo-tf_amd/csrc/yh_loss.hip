@@ -125,6 +125,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         const uint32_t cy = cell / (uint32_t)W, cx = cell - cy * (uint32_t)W;
         const bool occupied = (s_occ[cell >> 5] >> (cell & 31)) & 1u;
         float m = __builtin_nanf("");
+        bool counted = false;                 // the box enters the no-object sum
         if (!occupied) {
             // YOLOv3.py:246-257: L = a_yx - a_hw/2 and U = a_yx + a_hw/2 are then used
             // as (centre, size): corners L - U/2 and L + U/2.
@@ -149,7 +150,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                     else if (iou > m) m = iou;
                 }
                 if (any_nan) m = __builtin_nanf("");
-                if (m <= p.ignore_thr) contrib = sigmoid_ce(obj, 0.0f);
+                counted = m <= p.ignore_thr;
             } else {
                 // Branch-free pass: sign(uni) * inter against thr * |uni| with a relative margin of
                 // 2^-20 on either side (the roundings involved are below 2^-23).  Pairs inside the
@@ -181,10 +182,12 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                         masked |= (iou != iou) | (iou > thr);
                     }
                 }
-                if (!masked) contrib = sigmoid_ce(obj, 0.0f);
+                counted = !masked;
             }
         }
+        if (counted) contrib = sigmoid_ce(obj, 0.0f);
         if (EXACT_MAX) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
+        if (p.noobj_mask) p.noobj_mask[(long long)b * p.N + sc.row_base + row] = counted ? 1 : 0;
     }
 
     // block sum, fixed order
@@ -197,6 +200,72 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         for (int w = 1; w < kLossNegThreads / 64; ++w) acc += s_val[w];
         p.neg_partial[(long long)b * p.blocks_per_img + r] = acc;
     }
+}
+
+// Target assignment of one ground-truth row (yc, xc, h, w, class in pixels): best
+// prior per scale by the reference's IoU (YOLOv3.py:159-177: intersection not
+// clamped, anchor area = prod(hw); argmax = first maximum), then the scale
+// (YOLOv3.py:185-189: scale s < S-1 takes the GT when it beats every other scale
+// strictly; everything else goes to the last scale).  All wave-uniform.
+struct GtAssign {
+    int s, p;            // scale and prior
+    uint32_t row;        // box row inside the scale: (cy * W + cx) * P + p
+    int label;
+    float gy, gx, gh, gw;   // the GT in grid units of scale s
+    bool inside;         // the centre's cell lies inside the grid
+};
+
+__device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *gtrow)
+{
+    const int S = p.S, P = p.P;
+    const float y = gtrow[0], x = gtrow[1], h = gtrow[2], w = gtrow[3];
+    GtAssign a;
+    a.label = (int)gtrow[4];                                  // tf.cast(float -> int32) truncates
+    float best_iou[YH_MAX_SCALES];
+    int best_p[YH_MAX_SCALES];
+#pragma unroll
+    for (int s = 0; s < YH_MAX_SCALES; ++s) {
+        best_iou[s] = 0.0f; best_p[s] = 0;
+        if (s < S) {
+            const float rate = p.sc[s].gt_rate;
+            const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
+            const float ay = floorf(gy) + 0.5f, ax = floorf(gx) + 0.5f;
+            const float gy1 = gy - gh / 2.0f, gx1 = gx - gw / 2.0f;
+            const float gy2 = gy + gh / 2.0f, gx2 = gx + gw / 2.0f;
+            const float garea = (gy2 - gy1) * (gx2 - gx1);
+            for (int q = 0; q < P; ++q) {
+                const float ah = p.sc[s].prior_hw[q][0], aw = p.sc[s].prior_hw[q][1];
+                const float ay1 = ay - ah / 2.0f, ax1 = ax - aw / 2.0f;
+                const float ay2 = ay + ah / 2.0f, ax2 = ax + aw / 2.0f;
+                const float inter = (fminf(gy2, ay2) - fmaxf(gy1, ay1)) * (fminf(gx2, ax2) - fmaxf(gx1, ax1));
+                const float iou = inter / ((ah * aw + garea) - inter);
+                if (q == 0 || iou > best_iou[s]) { best_iou[s] = iou; best_p[s] = q; }
+            }
+        }
+    }
+    int ssel = S - 1;
+    bool found = false;
+#pragma unroll
+    for (int s = 0; s < YH_MAX_SCALES; ++s) {
+        if (s < S - 1 && !found) {
+            bool wins = true;
+#pragma unroll
+            for (int t = 0; t < YH_MAX_SCALES; ++t)
+                if (t < S && t != s && !(best_iou[s] > best_iou[t])) wins = false;
+            if (wins) { ssel = s; found = true; }
+        }
+    }
+    int psel = 0;
+#pragma unroll
+    for (int s = 0; s < YH_MAX_SCALES; ++s) if (s == ssel) psel = best_p[s];
+    const LossScale &sc = p.sc[ssel];
+    const float rate = sc.gt_rate;
+    a.s = ssel; a.p = psel;
+    a.gy = y / rate; a.gx = x / rate; a.gh = h / rate; a.gw = w / rate;
+    const int cy = (int)floorf(a.gy), cx = (int)floorf(a.gx);
+    a.inside = cy >= 0 && cy < sc.H && cx >= 0 && cx < sc.W;
+    a.row = a.inside ? (uint32_t)((cy * sc.W + cx) * P + psel) : 0u;
+    return a;
 }
 
 // ---------------------------------------------------------------- positive
@@ -216,68 +285,24 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     const int g = blk * kLossPosGtPerBlock + wave;
     float coord = 0.0f, cls = 0.0f, obj = 0.0f;
     if (g < G) {
-        const int S = p.S, P = p.P, C = p.C, K = p.K;
-        const float y = gt[g * 5 + 0], x = gt[g * 5 + 1], h = gt[g * 5 + 2], w = gt[g * 5 + 3];
-        const int label = (int)gt[g * 5 + 4];                 // tf.cast(float -> int32) truncates
-        float best_iou[YH_MAX_SCALES];
-        int best_p[YH_MAX_SCALES];
-#pragma unroll
-        for (int s = 0; s < YH_MAX_SCALES; ++s) {
-            best_iou[s] = 0.0f; best_p[s] = 0;
-            if (s < S) {
-                const float rate = p.sc[s].gt_rate;
-                const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
-                const float ay = floorf(gy) + 0.5f, ax = floorf(gx) + 0.5f;
-                const float gy1 = gy - gh / 2.0f, gx1 = gx - gw / 2.0f;
-                const float gy2 = gy + gh / 2.0f, gx2 = gx + gw / 2.0f;
-                const float garea = (gy2 - gy1) * (gx2 - gx1);
-                for (int q = 0; q < P; ++q) {
-                    const float ah = p.sc[s].prior_hw[q][0], aw = p.sc[s].prior_hw[q][1];
-                    const float ay1 = ay - ah / 2.0f, ax1 = ax - aw / 2.0f;
-                    const float ay2 = ay + ah / 2.0f, ax2 = ax + aw / 2.0f;
-                    // YOLOv3.py:159-177: intersection not clamped, anchor area = prod(hw)
-                    const float inter = (fminf(gy2, ay2) - fmaxf(gy1, ay1)) * (fminf(gx2, ax2) - fmaxf(gx1, ax1));
-                    const float iou = inter / ((ah * aw + garea) - inter);
-                    if (q == 0 || iou > best_iou[s]) { best_iou[s] = iou; best_p[s] = q; }   // argmax: first maximum
-                }
-            }
-        }
-        // YOLOv3.py:185-189: scale s < S-1 takes the GT when it beats every other scale
-        // strictly; everything else goes to the last scale.
-        int ssel = S - 1;
-        bool found = false;
-#pragma unroll
-        for (int s = 0; s < YH_MAX_SCALES; ++s) {
-            if (s < S - 1 && !found) {
-                bool wins = true;
-#pragma unroll
-                for (int t = 0; t < YH_MAX_SCALES; ++t)
-                    if (t < S && t != s && !(best_iou[s] > best_iou[t])) wins = false;
-                if (wins) { ssel = s; found = true; }
-            }
-        }
-        int psel = 0;
-#pragma unroll
-        for (int s = 0; s < YH_MAX_SCALES; ++s) if (s == ssel) psel = best_p[s];
-        const LossScale &sc = p.sc[ssel];
-        const float rate = sc.gt_rate;
-        const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
-        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
-        if (cy >= 0 && cy < sc.H && cx >= 0 && cx < sc.W) {
-            const float *rowp = sc.head + ((((long long)b * sc.H + cy) * sc.W + cx) * P + psel) * K;
+        const int C = p.C, K = p.K;
+        const GtAssign a = assign_gt(p, gt + g * 5);
+        if (a.inside) {
+            const LossScale &sc = p.sc[a.s];
+            const float *rowp = sc.head + (long long)b * sc.rows_img * K + (long long)a.row * K;
             for (int k = lane; k < K; k += 64) {
                 const float v = rowp[k];
                 if (k < C) {
-                    cls += sigmoid_ce(v, k == label ? 1.0f : 0.0f);
+                    cls += sigmoid_ce(v, k == a.label ? 1.0f : 0.0f);
                 } else if (k == C) {
-                    coord += sigmoid_ce(v, gy - floorf(gy));
+                    coord += sigmoid_ce(v, a.gy - floorf(a.gy));
                 } else if (k == C + 1) {
-                    coord += sigmoid_ce(v, gx - floorf(gx));
+                    coord += sigmoid_ce(v, a.gx - floorf(a.gx));
                 } else if (k == C + 2) {
-                    const float d = v - logf(gh / sc.prior_hw[psel][0]);
+                    const float d = v - logf(a.gh / sc.prior_hw[a.p][0]);
                     coord += 0.5f * (d * d);
                 } else if (k == C + 3) {
-                    const float d = v - logf(gw / sc.prior_hw[psel][1]);
+                    const float d = v - logf(a.gw / sc.prior_hw[a.p][1]);
                     coord += 0.5f * (d * d);
                 } else {
                     obj += sigmoid_ce(v, 1.0f);
@@ -365,6 +390,101 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossPa
         for (int w = 0; w < kFinalizeThreads / 64; ++w) acc += s_sum[w];
         *p.loss_sum = (float)acc;
     }
+}
+
+// ---------------------------------------------------------------- backward
+// d(sum_b grad_w[b] * loss_per_image[b]) / d(head), closed form:
+//   no-object term   w_noobj * sigmoid(obj)                          on the boxes of noobj_mask
+//   assigned rows    w_class * (sigmoid(x_k) - [k == label]), w_coord * (sigmoid(t_yx) - frac),
+//                    w_coord * (t_hw - log(g_hw / prior_hw)), w_obj * (sigmoid(obj) - 1)
+// each divided by the image's GT count when normalize is set.
+//
+// k_loss_grad_fill writes the whole gradient tensor (zeros and the objectness column of the
+// no-object boxes): a workgroup owns 256 consecutive rows, the row owners compute the column,
+// then all threads store the rows' K floats as one contiguous, coalesced run.  Bound: HBM write.
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossParams p)
+{
+    __shared__ float s_g[kLossNegThreads];
+    __shared__ float s_val[kLossNegThreads / 64];
+    __shared__ int s_idx[kLossNegThreads / 64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / p.blocks_per_img;
+    const uint32_t r = blockIdx.x - (uint32_t)b * p.blocks_per_img;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && r >= p.sc[i].blk_begin) s = i;
+    const LossScale &sc = p.sc[s];
+    const uint32_t row0 = (r - sc.blk_begin) * kLossNegThreads;
+    const uint32_t row = row0 + tid;
+    const int C = p.C, K = p.K;
+    float g = 0.0f;
+    const bool in_range = row < sc.rows_img;
+    float obj = 0.0f;
+    int counted = 0;
+    if (in_range) {
+        obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
+        counted = p.noobj_mask[(long long)b * p.N + sc.row_base + row];
+    }
+    const int G = block_gt_count(p.gt + (long long)b * p.pad * 5, p.pad, s_val, s_idx, kLossNegThreads);
+    float scale = p.w_noobj * p.grad_w[b];
+    if (p.normalize) scale = scale / (float)G;
+    if (counted) g = sigmoidf(obj) * scale;
+    s_g[tid] = g;
+    __syncthreads();
+    const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegThreads ? sc.rows_img - row0 : (uint32_t)kLossNegThreads;
+    float *dst = sc.grad + ((long long)b * sc.rows_img + row0) * K;
+    const uint32_t total = nrows * (uint32_t)K;
+    for (uint32_t e = tid; e < total; e += kLossNegThreads) {
+        const uint32_t rr = e / (uint32_t)K;
+        const uint32_t k = e - rr * (uint32_t)K;
+        dst[e] = k == (uint32_t)(C + 4) ? s_g[rr] : 0.0f;
+    }
+}
+
+// Adds the assigned rows' terms (atomically: several GT rows may share a box).  Runs after
+// k_loss_grad_fill on the same stream.  One wavefront per GT row.
+__global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams p)
+{
+    __shared__ float s_val[kPosThreads / 64];
+    __shared__ int s_idx[kPosThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)(blockIdx.x / (uint32_t)p.pos_blocks);
+    const int blk = (int)blockIdx.x - b * p.pos_blocks;
+    const float *gt = p.gt + (long long)b * p.pad * 5;
+    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+    const int g = blk * kLossPosGtPerBlock + wave;
+    if (g >= G) return;
+    const int C = p.C, K = p.K;
+    const GtAssign a = assign_gt(p, gt + g * 5);
+    if (!a.inside) return;
+    const LossScale &sc = p.sc[a.s];
+    float w = p.grad_w[b];
+    if (p.normalize) w = w / (float)G;
+    const long long at = (long long)b * sc.rows_img * K + (long long)a.row * K;
+    const float *rowp = sc.head + at;
+    float *grow = sc.grad + at;
+    for (int k = lane; k < K; k += 64) {
+        const float v = rowp[k];
+        float d;
+        if (k < C) d = p.w_class * (sigmoidf(v) - (k == a.label ? 1.0f : 0.0f));
+        else if (k == C) d = p.w_coord * (sigmoidf(v) - (a.gy - floorf(a.gy)));
+        else if (k == C + 1) d = p.w_coord * (sigmoidf(v) - (a.gx - floorf(a.gx)));
+        else if (k == C + 2) d = p.w_coord * (v - logf(a.gh / sc.prior_hw[a.p][0]));
+        else if (k == C + 3) d = p.w_coord * (v - logf(a.gw / sc.prior_hw[a.p][1]));
+        else d = p.w_obj * (sigmoidf(v) - 1.0f);
+        atomicAdd(&grow[k], d * w);
+    }
+}
+
+hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
+{
+    if (p.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loss_grad_fill, dim3((uint32_t)p.B * (uint32_t)p.blocks_per_img), dim3(kLossNegThreads), 0, stm, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss_grad_pos, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks), dim3(kPosThreads), 0, stm, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_loss(const LossParams &p, hipStream_t stm)

@@ -274,10 +274,12 @@ class DetectionHead:
 
     # --------------------------------------------------------------- loss
     def loss(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
-             ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False):
+             ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False):
         """Per-image training loss (YOLOv3.py:117-310 / YOLOv2.py:105-173).
         ground_truth: [B, pad, 5] float32 CUDA tensor, -1 padded.
-        Returns dict(per_image [B], sum [1], parts [B,4] | None, iou_max [B,N] | None)."""
+        Returns dict(per_image [B], sum [1], parts [B,4] | None, iou_max [B,N] | None,
+        noobj_mask [B,N] uint8 | None: what loss_backward needs).  No autograd
+        graph is recorded here: loss_with_grad does that."""
         lib = _abi.load()
         heads = self._check_heads(heads)
         cfg = self.config_for(heads)
@@ -296,15 +298,73 @@ class DetectionHead:
         total = torch.empty((1,), dtype=torch.float32, device=dev)
         parts = torch.empty((B, 4), dtype=torch.float32, device=dev) if want_parts else None
         iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
+        mask = torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None
         scales = (ctypes.c_float * 4)(float(coord_scale), float(noobj_scale), float(obj_scale), float(class_scale))
         with torch.cuda.device(dev):
-            _abi.check(lib.yh_loss(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
-                                   gt.data_ptr(), B, pad, scales, float(ignore_threshold),
-                                   1 if normalize_by_num_gt else 0, ws.data_ptr(), ws.numel(),
-                                   per.data_ptr(), parts.data_ptr() if want_parts else None,
-                                   iou.data_ptr() if want_iou_max else None, total.data_ptr(),
-                                   self._stream(dev)))
-        return dict(per_image=per, sum=total, parts=parts, iou_max=iou)
+            _abi.check(lib.yh_loss_forward(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
+                                           gt.data_ptr(), B, pad, scales, float(ignore_threshold),
+                                           1 if normalize_by_num_gt else 0, ws.data_ptr(), ws.numel(),
+                                           per.data_ptr(), parts.data_ptr() if want_parts else None,
+                                           iou.data_ptr() if want_iou_max else None, total.data_ptr(),
+                                           mask.data_ptr() if want_mask else None, self._stream(dev)))
+        return dict(per_image=per, sum=total, parts=parts, iou_max=iou, noobj_mask=mask)
+
+    def loss_backward(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                      normalize_by_num_gt, noobj_mask, grad_per_image):
+        """d(sum_b grad_per_image[b] * loss_per_image[b]) / d(head) for every head
+        tensor: the backward of loss() (what optimizer.minimize differentiates at
+        YOLOv3.py:312-318), from the forward call's inputs and noobj_mask."""
+        lib = _abi.load()
+        heads = self._check_heads(heads)
+        cfg = self.config_for(heads)
+        dev = heads[0].device
+        gt = ground_truth.to(torch.float32).contiguous()
+        B, pad = heads[0].shape[0], int(gt.shape[1])
+        gw = grad_per_image.to(torch.float32).contiguous()
+        if gw.shape != (B,) or noobj_mask.shape != (B, self.boxes_per_image(heads)) or noobj_mask.dtype != torch.uint8:
+            raise ValueError('grad_per_image must be [B] and noobj_mask the uint8 [B, N] of the forward call')
+        grads = [torch.empty_like(h) for h in heads]
+        scales = (ctypes.c_float * 4)(float(coord_scale), float(noobj_scale), float(obj_scale), float(class_scale))
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_loss_backward(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
+                                            gt.data_ptr(), B, pad, scales, 1 if normalize_by_num_gt else 0,
+                                            noobj_mask.contiguous().data_ptr(), gw.data_ptr(),
+                                            _abi.pointer_array([g.data_ptr() for g in grads]), self._stream(dev)))
+        return grads
+
+    def loss_with_grad(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                       ignore_threshold, normalize_by_num_gt):
+        """(sum of the per-image losses [1], per-image losses [B]) as tensors that
+        carry an autograd graph back to `heads`."""
+        out = _HeadLoss.apply(self, ground_truth, (float(coord_scale), float(noobj_scale), float(obj_scale),
+                                                   float(class_scale)), float(ignore_threshold),
+                              bool(normalize_by_num_gt), *heads)
+        return out[0], out[1]
+
+
+class _HeadLoss(torch.autograd.Function):
+    """DetectionHead.loss / loss_backward as one differentiable op."""
+
+    @staticmethod
+    def forward(ctx, head_obj, ground_truth, scales, ignore_threshold, normalize, *heads):
+        heads = [h.detach() for h in heads]
+        out = head_obj.loss(heads, ground_truth, *scales, ignore_threshold, normalize, want_mask=True)
+        ctx.head_obj, ctx.scales, ctx.normalize = head_obj, scales, normalize
+        ctx.save_for_backward(ground_truth, out['noobj_mask'], *heads)
+        return out['sum'], out['per_image']
+
+    @staticmethod
+    def backward(ctx, grad_sum, grad_per):
+        ground_truth, mask = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        heads = list(ctx.saved_tensors[2:])
+        B = heads[0].shape[0]
+        gw = torch.zeros((B,), dtype=torch.float32, device=heads[0].device)
+        if grad_sum is not None:
+            gw = gw + grad_sum.reshape(()).to(torch.float32)
+        if grad_per is not None:
+            gw = gw + grad_per.to(torch.float32)
+        grads = ctx.head_obj.loss_backward(heads, ground_truth, *ctx.scales, ctx.normalize, mask, gw)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 

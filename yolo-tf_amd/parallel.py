@@ -35,6 +35,13 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def global_batch(local_batch):
+    """Images of the step over all ranks (every rank holds local_batch of them)."""
+    if dist.is_available() and dist.is_initialized():
+        return int(local_batch) * dist.get_world_size()
+    return int(local_batch)
+
+
 def global_mean_loss(local_sum, local_batch):
     """reduce_mean over the global batch.  local_sum: tensor [1] (or 0-dim)
     holding this rank's sum of per-image losses.  Returns a 0-dim float32

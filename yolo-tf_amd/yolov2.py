@@ -109,6 +109,21 @@ class YOLOv2:
         total = parallel.global_mean_loss(out['sum'], head.shape[0])
         return (total, out) if want_parts else total
 
+    def _train_step(self, head, ground_truth, lr):
+        """One optimisation step when the head tensor carries an autograd graph
+        (optimizer.minimize, YOLOv2.py:175-181); see YOLOv3._train_step."""
+        total_sum, _ = self.head.loss_with_grad([head], ground_truth, self.coord_sacle, self.noobj_scale,
+                                                self.obj_scale, self.class_scale, 0.6, False)
+        local_b = head.shape[0]
+        zero = getattr(self.head_provider, 'zero_grad', None)
+        if zero is not None:
+            zero()
+        (total_sum.reshape(()) / parallel.global_batch(local_b)).backward()
+        step = getattr(self.head_provider, 'step', None)
+        if step is not None:
+            step(lr)
+        return parallel.global_mean_loss(total_sum.detach(), local_b)
+
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)
         return float(fn()) if fn is not None else 0.0
@@ -122,7 +137,11 @@ class YOLOv2:
         for i in range(num_iters):
             images, ground_truth = next(self.train_iterator)
             self.ground_truth = ground_truth
-            total_loss = self.loss_from_heads(self._head_from(images), ground_truth)
+            head = self._head_from(images)
+            if head.requires_grad:
+                total_loss = self._train_step(head, ground_truth, lr)
+            else:                                            # a head without a graph: the loss value only
+                total_loss = self.loss_from_heads(head, ground_truth)
             # YOLOv2.py:176-178: total_loss + weight_decay * sum(l2_loss(var))
             loss = np.float32(float(total_loss.item()) + self.weight_decay * self._weight_l2())
             self.loss = loss

@@ -137,6 +137,24 @@ class YOLOv3:
         total = parallel.global_mean_loss(out['sum'], heads[0].shape[0])
         return (total, out) if want_parts else total
 
+    def _train_step(self, heads, ground_truth, lr, loss_factor):
+        """One optimisation step when the head tensors carry an autograd graph
+        (optimizer.minimize, YOLOv3.py:312-318): backward of loss_factor *
+        total_loss through the fused loss into the provider's network, then the
+        provider's `step(lr)`.  The weight-decay term belongs to the provider,
+        which owns the weights.  Returns total_loss (global mean, detached)."""
+        total_sum, _ = self.head.loss_with_grad(heads, ground_truth, self.coord_sacle, self.noobj_scale,
+                                                self.obj_scale, self.class_scale, 0.5, True)
+        local_b = heads[0].shape[0]
+        zero = getattr(self.head_provider, 'zero_grad', None)
+        if zero is not None:
+            zero()
+        (loss_factor * total_sum.reshape(()) / parallel.global_batch(local_b)).backward()
+        step = getattr(self.head_provider, 'step', None)
+        if step is not None:
+            step(lr)
+        return parallel.global_mean_loss(total_sum.detach(), local_b)
+
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)
         return float(fn()) if fn is not None else 0.0
@@ -152,7 +170,10 @@ class YOLOv3:
             images, ground_truth = next(self.train_iterator)
             self.ground_truth = ground_truth
             heads = self._heads_from(images)
-            total_loss = self.loss_from_heads(heads, ground_truth)
+            if any(h.requires_grad for h in heads):
+                total_loss = self._train_step(heads, ground_truth, lr, 0.5)
+            else:                                            # heads without a graph: the loss value only
+                total_loss = self.loss_from_heads(heads, ground_truth)
             # YOLOv3.py:313-315: .5 * total_loss + weight_decay * sum(l2_loss(var))
             loss = np.float32(.5 * float(total_loss.item()) + self.weight_decay * self._weight_l2())
             self.loss = loss

@@ -12,6 +12,7 @@ no collective and the loss workload all-reduces one scalar over RCCL.
 Workloads (BASELINE.json configs):
   detect416  config 2  YOLOv3-416 COCO-80, batch 64 / GPU, decode + score filter + per-class NMS   [default]
   loss416    config 3  YOLOv3-416 loss, 100 GT / image, batch 32 / GPU
+  train416   config 3 with the backward to the head tensors (reads the head twice, writes its gradient)
   detect608  config 4  YOLOv3-608 COCO-80, batch 64 / GPU
   stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 16 / GPU
 
@@ -48,6 +49,8 @@ WORKLOADS = {
                    name='NMS stress: 100x100 grid x 10 priors, ~1e5 candidates/img at score_thresh 0.001, 80 classes'),
     'loss416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101,
                     name='YOLOv3 416x416 training loss path: 100 GT boxes/img IoU ignore-mask + target assignment'),
+    'train416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101, backward=True,
+                     name='YOLOv3 416x416 training loss path, forward + backward to the head tensors (autograd)'),
 }
 
 
@@ -153,7 +156,19 @@ def main():
         gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
                for i in range(ROTATE)]
 
+        if w.get('backward'):
+            for hs in sets:
+                for h in hs:
+                    h.requires_grad_(True)
+
         def step(i, events=None):
+            if w.get('backward'):
+                hs = sets[i % ROTATE]
+                for h in hs:
+                    h.grad = None
+                total, _ = hd.loss_with_grad(hs, gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
+                (0.5 * total.reshape(()) / y.parallel.global_batch(B)).backward()
+                return y.parallel.global_mean_loss(total.detach(), B)
             out = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
             return y.parallel.global_mean_loss(out['sum'], B)   # the data-parallel scalar all-reduce
         extra = {}

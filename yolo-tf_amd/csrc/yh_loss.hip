@@ -435,10 +435,29 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossPa
     const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegThreads ? sc.rows_img - row0 : (uint32_t)kLossNegThreads;
     float *dst = sc.grad + ((long long)b * sc.rows_img + row0) * K;
     const uint32_t total = nrows * (uint32_t)K;
-    for (uint32_t e = tid; e < total; e += kLossNegThreads) {
+    const uint32_t objk = (uint32_t)(C + 4);
+    auto value = [&](uint32_t rr, uint32_t k) { return k == objk ? s_g[rr] : 0.0f; };
+    // 16-byte stores over the aligned body of the run, single floats at its ends
+    uint32_t head = (4u - (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3u)) & 3u;
+    head = head < total ? head : total;
+    if ((uint32_t)tid < head) dst[tid] = value(0u, (uint32_t)tid);        // head < 4 <= K: still row 0
+    const uint32_t nb = (total - head) >> 2;
+    float4 *dst4 = reinterpret_cast<float4 *>(dst + head);
+    for (uint32_t i = tid; i < nb; i += kLossNegThreads) {
+        const uint32_t e0 = head + 4u * i;
+        uint32_t rr = e0 / (uint32_t)K, k = e0 - rr * (uint32_t)K;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = value(rr, k);
+            if (++k == (uint32_t)K) { k = 0; ++rr; }
+        }
+        dst4[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const uint32_t e = head + 4u * nb + (uint32_t)tid;
+    if (e < total) {
         const uint32_t rr = e / (uint32_t)K;
-        const uint32_t k = e - rr * (uint32_t)K;
-        dst[e] = k == (uint32_t)(C + 4) ? s_g[rr] : 0.0f;
+        dst[e] = value(rr, e - rr * (uint32_t)K);
     }
 }
 

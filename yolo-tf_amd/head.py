@@ -357,12 +357,8 @@ class _HeadLoss(torch.autograd.Function):
     def backward(ctx, grad_sum, grad_per):
         ground_truth, mask = ctx.saved_tensors[0], ctx.saved_tensors[1]
         heads = list(ctx.saved_tensors[2:])
-        B = heads[0].shape[0]
-        gw = torch.zeros((B,), dtype=torch.float32, device=heads[0].device)
-        if grad_sum is not None:
-            gw = gw + grad_sum.reshape(()).to(torch.float32)
-        if grad_per is not None:
-            gw = gw + grad_per.to(torch.float32)
+        # upstream weight of every per-image loss: through `per_image` and through `sum`
+        gw = grad_per + grad_sum.reshape(())
         grads = ctx.head_obj.loss_backward(heads, ground_truth, *ctx.scales, ctx.normalize, mask, gw)
         return (None, None, None, None, None) + tuple(grads)
 

@@ -99,3 +99,33 @@ def test_two_rank_gloo_loss_mean_matches_full_batch():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('GLOO_OK') == 2, r.stdout + r.stderr
+
+
+def test_ground_truth_wire_format_round_trip():
+    """utils/image_augmentor.py:205-244: centre filter, clamp, (yc, xc, h, w, class), -1 padding."""
+    boxes = [[10, 20, 50, 80], [-30, -30, 10, 10], [400, 400, 430, 440], [390, 10, 430, 60]]
+    cls = [3, 5, 7, 9]
+    blk = y.wire.encode_ground_truth(boxes, cls, (416, 416), 6)
+    assert blk.shape == (6, 5) and blk.dtype == np.float32
+    # box 1: centre (-10, -10) outside; box 2: centre (415, 420): x centre beyond 415 -> dropped
+    assert np.array_equal(blk[0], np.float32([30, 50, 40, 60, 3]))
+    # box 3 is clamped to 415 before centre and size are taken
+    assert np.array_equal(blk[1], np.float32([(390 + 415) / 2., 35, 25, 50, 9]))
+    assert np.all(blk[2:] == -1)
+    b2, c2 = y.wire.decode_ground_truth(blk)
+    assert np.array_equal(c2, [3, 9]) and np.allclose(b2[0], [10, 20, 50, 80])
+    from oracle import yolo_head_oracle as O
+    yx, hw, lab = O.normalized_gn(blk, 32.0)
+    assert yx.shape == (2, 2) and np.array_equal(lab, [3, 9])
+    with pytest.raises(ValueError):
+        y.wire.encode_ground_truth(boxes[:1] * 6, [1] * 6, (416, 416), 6)      # no pad row left
+    batch = y.wire.encode_ground_truth_batch([boxes, boxes[:1]], [cls, cls[:1]], (416, 416), 6)
+    assert batch.shape == (2, 6, 5) and np.all(batch[1, 1:] == -1)
+    assert y.wire.encode_ground_truth([], [], (416, 416), 4).tolist() == [[-1.0] * 5] * 4
+
+
+def test_detection_records_and_voc_names():
+    assert len(y.wire.VOC_CLASSNAMES) == 20 and y.wire.classname_to_ids['tvmonitor'] == 19
+    rec = y.wire.detections_to_records([0.9], [[1, 2, 3, 4]], [14])
+    assert rec == [dict(name='person', class_id=14, score=0.9 if False else rec[0]['score'], y1=1.0, x1=2.0, y2=3.0, x2=4.0)]
+    assert abs(rec[0]['score'] - 0.9) < 1e-7

@@ -113,12 +113,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank, world, local_rank = y.parallel.init_from_env()
+    # YH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    rank, world, local_rank = y.parallel.init_from_env(os.environ.get('YH_DIST_BACKEND'))
     if world != max(1, args.gpus):
         raise SystemExit('--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the path has no CPU fallback')
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     w = dict(WORKLOADS[args.workload])

@@ -29,7 +29,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank

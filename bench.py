@@ -13,6 +13,7 @@ Workloads (BASELINE.json configs):
   detect416  config 2  YOLOv3-416 COCO-80, batch 64 / GPU, decode + score filter + per-class NMS   [default]
   loss416    config 3  YOLOv3-416 loss, 100 GT / image, batch 32 / GPU
   train416   config 3 with the backward to the head tensors (reads the head twice, writes its gradient)
+  detect_v2  config 1  YOLOv2-416 VOC-20, batch 1 (latency-bound: one image)
   detect608  config 4  YOLOv3-608 COCO-80, batch 64 / GPU
   stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 16 / GPU
 
@@ -43,6 +44,8 @@ ROTATE = 4                       # distinct input sets, so that no step re-reads
 WORKLOADS = {
     'detect416': dict(kind='detect', size=416, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
                       name='YOLOv3 416x416 COCO-80 decode+NMS, synthetic head tensors, 10647 boxes/img'),
+    'detect_v2': dict(kind='detect', size=416, C=20, batch=1, thr=0.5, iou=0.5, max_boxes=10, dist={}, version=2,
+                      name='YOLOv2 416x416 VOC-20 batch 1 decode+NMS (the reference\'s own CPU-runnable case), 845 boxes/img'),
     'detect608': dict(kind='detect', size=608, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
                       name='YOLOv3 608x608 COCO-80 decode+NMS, synthetic head tensors, 22743 boxes/img'),
     'stress': dict(kind='detect', size=None, C=80, batch=16, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
@@ -60,6 +63,9 @@ def build_head(w):
         priors = [rng.uniform(0.5, 4.0, size=(10, 2)).astype(np.float32)]
         grids = [(100, 100)]
         return grids, priors, (32.0,), (32.0,)
+    if w.get('version') == 2:
+        g = w['size'] // 32
+        return [(g, g)], [np.asarray(y.synth.V2_PRIORS, np.float32)], (32.0,), (32.0,)
     s = [8., 16., 32.]
     priors = [(np.asarray(y.synth.V3_PRIORS[i], np.float32) / np.float32(s[i])) for i in range(3)]
     return y.synth.v3_grids(w['size']), priors, (32.0, 32.0, 16.0), (32.0, 16.0, 8.0)
@@ -88,6 +94,27 @@ def cpu_baseline(w, grids, priors, box_mult, gt_rate, budget_s=12.0):
     return dict(value=round(Bs * reps / el, 2), unit='images/sec', cores=threads, kind='port',
                 sample='%d synthetic images x %d passes (%.1f s) of the same workload, C restatement of the '
                        'reference op sequence (oracle/yolo_head_oracle.c), OpenMP over images' % (Bs, reps, el))
+
+
+def measured_read_bandwidth(sets, dev, reps=20):
+    """GB/s a read-only kernel reaches on these very buffers (yh_probe_read, HIP events): the
+    achievable figure next to the nominal peak."""
+    import ctypes
+    lib = y._abi.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    bufs = [h for hs in sets for h in hs if h.numel() * 4 >= (32 << 20)] or [max((h for hs in sets for h in hs), key=lambda t: t.numel())]
+    for h in bufs:
+        y._abi.check(lib.yh_probe_read(h.data_ptr(), h.numel() * 4, st))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    nbytes = 0
+    for i in range(reps):
+        h = bufs[i % len(bufs)]
+        y._abi.check(lib.yh_probe_read(h.data_ptr(), h.numel() * 4, st))
+        nbytes += h.numel() * 4
+    b.record()
+    torch.cuda.synchronize(dev)
+    return nbytes / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
 def load_traffic(workload):
@@ -267,6 +294,8 @@ def main():
                                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
                                    kernel='whole loss step (k_loss_main + k_loss_finalize + the scalar mean), wall clock',
                                    algorithmic_bytes_per_launch=B * bytes_img)
+        res['roofline']['achievable_read_gbs'] = round(measured_read_bandwidth(sets, dev), 1)
+        res['roofline']['frac_of_achievable'] = round(res['roofline']['achieved'] / res['roofline']['achievable_read_gbs'], 4)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(w, grids, priors, box_mult, gt_rate)
         print(json.dumps(res), flush=True)

@@ -76,6 +76,12 @@ const char *yh_last_error(void);
  * runtime reports none: there is no CPU fallback. */
 int yh_device_count(int32_t *count);
 
+/* Streams `bytes` bytes at device pointer `src` (16-byte aligned) through a
+ * kernel that only reads them.  Measurement hook (no counterpart in the
+ * reference): timed by a benchmark it gives the read bandwidth this chip
+ * delivers to a kernel, the yardstick next to the nominal HBM peak. */
+int yh_probe_read(const void *src, size_t bytes, void *stream);
+
 /* N = sum_s H_s * W_s * P (host out). */
 int yh_boxes_per_image(const yh_head_config *cfg, int64_t *n);
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     'yh_version': (ctypes.c_int, []),
     'yh_last_error': (ctypes.c_char_p, []),
     'yh_device_count': (ctypes.c_int, [ctypes.POINTER(_I)]),
+    'yh_probe_read': (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     'yh_boxes_per_image': (ctypes.c_int, [_CFG, ctypes.POINTER(ctypes.c_int64)]),
     'yh_decode': (ctypes.c_int, [_CFG, _PP, _I, _P, _P, _P]),
     'yh_detect_workspace_bytes': (ctypes.c_int, [_CFG, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)]),

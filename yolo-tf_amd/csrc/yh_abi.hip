@@ -272,6 +272,17 @@ int yh_device_count(int32_t *count)
     return YH_OK;
 }
 
+int yh_probe_read(const void *src, size_t bytes, void *stream)
+{
+    if (!src && bytes) return fail(YH_ERR_INVALID_ARG, "src is null");
+    if (reinterpret_cast<uintptr_t>(src) & 15u) return fail(YH_ERR_ALIGN, "src is not 16-byte aligned");
+    const int rc = ensure_device();
+    if (rc != YH_OK) return rc;
+    const hipError_t e = yh::launch_probe_read(src, bytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "probe launch");
+    return YH_OK;
+}
+
 int yh_boxes_per_image(const yh_head_config *cfg, int64_t *n)
 {
     if (!n) return fail(YH_ERR_INVALID_ARG, "n is null");

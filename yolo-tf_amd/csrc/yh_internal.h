@@ -87,6 +87,8 @@ struct StreamParams {
     StreamScale sc[YH_MAX_SCALES];
 };
 
+hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t st);
+
 constexpr int kTileFloats = 8192;                   // LDS tile of the streaming pass: 32 KiB
 
 enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };

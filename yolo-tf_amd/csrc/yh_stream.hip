@@ -487,6 +487,36 @@ static hipError_t launch_wave(const StreamParams &p, uint32_t blocks, hipStream_
     return hipGetLastError();
 }
 
+// Plain streaming read of a buffer (yh_probe_read): what the memory system delivers to a
+// kernel that only reads, the yardstick next to the nominal HBM peak.  Grid-stride, eight
+// 16-byte loads per lane in flight.
+__global__ __launch_bounds__(kThreads) void k_probe_read(const float4 *src, long long nslots, float *sink)
+{
+    float acc = 0.f;
+    const long long stride = (long long)gridDim.x * kThreads * 8;
+    for (long long base = (long long)blockIdx.x * kThreads * 8; base < nslots; base += stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            long long i = base + u * kThreads + threadIdx.x;
+            i = i < nslots ? i : nslots - 1;
+            v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
+    }
+    if (acc == 12345.678f && sink) sink[0] = acc;     // keeps the loads alive; never true for finite data in practice
+}
+
+hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t stm)
+{
+    const long long nslots = (long long)(bytes / 16);
+    if (nslots == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probe_read, dim3(1024), dim3(kThreads), 0, stm, static_cast<const float4 *>(src), nslots,
+                       static_cast<float *>(nullptr));
+    return hipGetLastError();
+}
+
 hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t stm, const NmsParams *fused)
 {
     if (fused && !(mode == kModeDetect && p.wave_ni)) return hipErrorInvalidValue;

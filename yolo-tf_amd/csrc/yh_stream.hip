@@ -29,7 +29,8 @@
 namespace yh {
 
 constexpr int kThreads = 256;
-constexpr int kStage = 512;      // candidate keys staged per workgroup
+constexpr int kStage = 384;      // candidate keys staged per workgroup
+constexpr int kHitCap = 1024;    // class logits that passed the prefilter, collected before they are worked on
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -38,7 +39,9 @@ struct Stage {
     float tile[kTileFloats];
     unsigned long long keys[kStage];
     uint16_t rows[kTileFloats / 6 + 1];   // rows that passed step A (K >= 6)
+    uint16_t hits[kHitCap];               // (row, class) items that passed the prefilter (item < kTileFloats)
     int nrows;
+    int nhits;
     int count;
     int base;
 };
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 {
     __shared__ __attribute__((aligned(16))) Stage st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { st.count = 0; st.nrows = 0; }
+    if (tid == 0) { st.count = 0; st.nrows = 0; st.nhits = 0; }
 
     int s = 0;
 #pragma unroll
@@ -161,26 +164,44 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         } else {
             nrows = rows_t;
         }
-        // ---- B: class logits of those rows, spread over all lanes
+        // ---- B: class logits of those rows, spread over all lanes.  Two steps per chunk of
+        // kHitCap items: the cheap prefilter collects the items that pass, then the lanes take
+        // the collected items densely.  (Doing the exact test where an item is found leaves one
+        // or two lanes of a wavefront working while the others wait: with dense candidates
+        // that made the kernel compute-bound at a few percent lane utilisation.)
         const int items = nrows * C;
-        for (int item = tid; item < items; item += kThreads) {
-            const int ri = item / C, c = item - ri * C;
-            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
-            const float *rp = tile + rr * K;
-            const float x = rp[c];
-            if (!(x >= pf)) continue;
-            const uint32_t row = row_t + (uint32_t)rr;
-            const int n = (int)(sc.row_base + row);
-            if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
-                push_candidate(st, p, b, make_key(c, x, n));
-            } else {
-                const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
-                if (cf >= p.thr) {
-                    reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
-                        decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
-                    push_candidate(st, p, b, make_key(c, cf, n));
+        for (int chunk0 = 0; chunk0 < items; chunk0 += kHitCap) {
+            const int chunk_end = chunk0 + kHitCap < items ? chunk0 + kHitCap : items;
+            for (int item = chunk0 + tid; item < chunk_end; item += kThreads) {
+                const int ri = item / C, c = item - ri * C;
+                const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+                if (tile[rr * K + c] >= pf) st.hits[atomicAdd(&st.nhits, 1)] = (uint16_t)item;
+            }
+            __syncthreads();
+            const int nhits = st.nhits;
+            for (int h = tid; h < nhits; h += kThreads) {
+                const int item = st.hits[h];
+                const int ri = item / C, c = item - ri * C;
+                const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+                const float *rp = tile + rr * K;
+                const float x = rp[c];
+                const uint32_t row = row_t + (uint32_t)rr;
+                const int n = (int)(sc.row_base + row);
+                if (MODE == kModeConf) {                      // the stream is the confidence matrix itself
+                    push_candidate(st, p, b, make_key(c, x, n));
+                } else {
+                    const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
+                    if (cf >= p.thr) {
+                        reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
+                            decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
+                        push_candidate(st, p, b, make_key(c, cf, n));
+                    }
                 }
             }
+            __syncthreads();
+            if (tid == 0) st.nhits = 0;
+            if (st.count >= kStage / 2) flush_candidates(st, p, b);   // uniform: count was read after a barrier
+            __syncthreads();
         }
         __syncthreads();
         if (tid == 0) st.nrows = 0;

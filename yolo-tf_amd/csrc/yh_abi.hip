@@ -223,6 +223,7 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
     p.S = cfg->num_scales; p.B = B; p.C = cfg->num_classes; p.P = cfg->num_priors;
     p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg);
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
+    p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
     uint32_t row_base = 0;
     for (int s = 0; s < p.S; ++s) {
         yh::StreamScale &sc = p.sc[s];
@@ -576,6 +577,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     std::memset(&p, 0, sizeof(p));
     p.S = 1; p.B = batch; p.C = num_classes; p.P = 1; p.K = num_classes; p.N = (int32_t)boxes_per_img;
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
+    p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
     p.thr = score_threshold;
     p.cand_cap = max_candidates;
     p.cand = w.cand;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         for (int chunk0 = 0; chunk0 < items; chunk0 += kHitCap) {
             const int chunk_end = chunk0 + kHitCap < items ? chunk0 + kHitCap : items;
             for (int item = chunk0 + tid; item < chunk_end; item += kThreads) {
-                const int ri = item / C, c = item - ri * C;
+                const int ri = (int)__umulhi((uint32_t)item, p.magic_c), c = item - ri * C;   // item < 2^13
                 const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
                 if (tile[rr * K + c] >= pf) st.hits[atomicAdd(&st.nhits, 1)] = (uint16_t)item;
             }

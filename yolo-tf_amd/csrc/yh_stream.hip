@@ -227,9 +227,17 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 //
 // Per tile: wait, one ds_read of the rows' objectness logits, one ballot, issue
 // the tile NBUF ahead.  Rows that pass the objectness prefilter (a few percent)
-// spread their class logits over the 64 lanes; candidates are compacted by
-// ballot into a wave-private stage and appended with one global atomic per
-// flush (normally one per work unit).
+// spread their class logits over the 64 lanes; candidates (key and decoded box)
+// are compacted by ballot into a wave-private stage.  At the end of its work
+// unit the wavefront stores them into the unit's kUnitSlots private slots and
+// kEmptySlot into the rest: plain stores, no atomic, nothing a later wavefront
+// has to wait for (one global atomic per unit on the 64 per-image counters cost
+// 5-14 us of a 46 us launch).  Only the 17th and later candidates of a unit
+// reserve a range of the image's list with a global atomic.
+//
+// This is the variant yh_detect uses unless a row is wider than a tile or the
+// caller's capacity announces dense candidates; the workgroup-tile kernel above
+// stays for those and for yh_nms.
 constexpr int kWaveStage = 128;   // staged keys per wave; flushed at >= 64, one step adds <= 64
 
 typedef __attribute__((address_space(3))) float lds_float_t;

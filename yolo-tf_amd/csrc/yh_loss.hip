@@ -62,6 +62,39 @@ __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx
     return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
 }
 
+// The image's ground-truth block [pad][5] staged in LDS with coalesced loads (one memory
+// round trip for everything the workgroup needs from it), and _get_normlized_gn's row count
+// (block_gt_count's result) taken from there.
+__device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int *s_idx, int nthreads)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < pad * 5; i += nthreads) s_gt[i] = gt[i];
+    __syncthreads();
+    float bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < pad; j += nthreads) {
+        const float v = s_gt[j * 5];
+        if (v < bv) { bv = v; bi = j; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(bv, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    float fv = s_val[0];
+    int fi = s_idx[0];
+    for (int w = 1; w < nthreads / 64; ++w) {
+        const float ov = s_val[w];
+        const int oi = s_idx[w];
+        if (ov < fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
+    }
+    __syncthreads();
+    return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
+}
+
 // ---------------------------------------------------------------- negative
 // B * blocks_per_img workgroups; one owns 256 consecutive box rows of one scale
 // of one image.  s_raw: 5 * pad floats (GT corners + area at this scale)
@@ -93,19 +126,15 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     const int C = p.C, K = p.K, P = p.P, H = sc.H, W = sc.W;
     const float *gt = p.gt + (long long)b * p.pad * 5;
 
-    // objectness logit first: its latency hides behind the prologue
-    float obj = 0.0f;
     const bool in_range = row < sc.rows_img;
-    if (in_range) obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
 
-    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kLossNegThreads);
     const int occ_words = (H * W + 31) >> 5;
     for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
-    __syncthreads();
+    const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
     const float rate = sc.gt_rate;
-    for (int g = tid; g < G; g += kLossNegThreads) {
-        const float gy = gt[g * 5 + 0] / rate, gx = gt[g * 5 + 1] / rate;
-        const float gh = gt[g * 5 + 2] / rate, gw = gt[g * 5 + 3] / rate;
+    for (int g = tid; g < G; g += kLossNegThreads) {           // row g is rewritten in place by its only reader
+        const float gy = s_gt[g * 5 + 0] / rate, gx = s_gt[g * 5 + 1] / rate;
+        const float gh = s_gt[g * 5 + 2] / rate, gw = s_gt[g * 5 + 3] / rate;
         const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
         const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
         s_gt[g * 5 + 0] = y1; s_gt[g * 5 + 1] = x1; s_gt[g * 5 + 2] = y2; s_gt[g * 5 + 3] = x2;
@@ -117,6 +146,12 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         }
     }
     __syncthreads();
+
+    // The objectness logit is asked for here, after the ground-truth round trip (memory loads
+    // return in issue order: an earlier request would hold that round trip back), and is not
+    // needed before the IoU loop below has run: the loop hides its latency.
+    float obj = 0.0f;
+    if (in_range) obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
 
     float contrib = 0.0f;
     if (in_range) {
@@ -152,12 +187,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                 if (any_nan) m = __builtin_nanf("");
                 counted = m <= p.ignore_thr;
             } else {
-                // Branch-free pass: sign(uni) * inter against thr * |uni| with a relative margin of
-                // 2^-20 on either side (the roundings involved are below 2^-23).  Pairs inside the
-                // margin, or with a zero, tiny or non-finite union, raise `recheck`.
+                // Branch-free pass.  With d = sign(uni) * inter - thr * |uni| (one rounding) and the
+                // margin m = 2^-20 * max(1, thr) * |uni| + 2^-100:  d > m implies RN(inter / uni) > thr
+                // and d < -m implies the opposite (the roundings involved stay below 2^-22 relative;
+                // the constant keeps tiny unions out).  Anything else (inside the margin, zero or
+                // non-finite operands: the comparisons are then both false) clears `decided`.
                 const float thr = p.ignore_thr;
-                const float thr_hi = thr * (1.0f + 0x1p-20f), thr_lo = thr * (1.0f - 0x1p-20f);
-                int masked = 0, recheck = thr >= 0.0f ? 0 : 1;
+                const float mfac = 0x1p-20f * fmaxf(1.0f, thr);
+                bool hit = false, decided = thr >= 0.0f;
                 for (int g = 0; g < G; ++g) {
                     const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
                     const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
@@ -166,11 +203,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                     const float uni = (aarea + garea) - inter;
                     const float au = fabsf(uni);
                     const float si = __uint_as_float(__float_as_uint(inter) ^ (__float_as_uint(uni) & 0x80000000u));
-                    const int valid = (au >= 0x1p-100f) & (au <= 3.4028235e38f);
-                    const int gt = si > thr_hi * au, le = si < thr_lo * au;
-                    masked |= valid & gt;
-                    recheck |= (valid & (gt | le)) ^ 1;
+                    const float d = __builtin_fmaf(-thr, au, si);
+                    const float m = __builtin_fmaf(mfac, au, 0x1p-100f);
+                    const bool above = d > m, below = d < -m;
+                    hit |= above;
+                    decided &= above | below;
                 }
+                int masked = hit ? 1 : 0;
+                const bool recheck = !decided;
                 if (recheck) {                    // rare: the exact walk decides
                     masked = 0;
                     for (int g = 0; g < G; ++g) {

@@ -14,6 +14,9 @@
 namespace yh {
 
 constexpr int kPosThreads = 64 * kLossPosGtPerBlock;
+constexpr int kPairStride = 12;              // floats per pair of ground-truth rows in LDS (16-byte aligned)
+constexpr float kLossFastBound = 0x1p40f;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // fminf / fmaxf as the bare instructions (IEEE mode: a NaN operand yields the other one, as
 // fminf / fmaxf do).  The compiler's own expansion first canonicalises operands it loaded from
@@ -111,8 +114,10 @@ template <bool EXACT_MAX>
 __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw,
                                                float *s_val, int *s_idx)
 {
-    float *s_gt = reinterpret_cast<float *>(s_raw);                 // [pad][5]: y1 x1 y2 x2 area
-    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_raw + (size_t)p.pad * 5 * sizeof(float));
+    // [ceil(pad/2)][12]: two ground-truth rows side by side, y1 y1' x1 x1' y2 y2' x2 x2' area area' - -
+    float *s_pair = reinterpret_cast<float *>(s_raw);
+    float *s_gt = s_pair + (size_t)((p.pad + 1) >> 1) * kPairStride;    // [pad][5]: y1 x1 y2 x2 area
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
 
     const int tid = threadIdx.x;
     const int b = block / p.blocks_per_img;
@@ -132,20 +137,32 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
     const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
     const float rate = sc.gt_rate;
+    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
     for (int g = tid; g < G; g += kLossNegThreads) {           // row g is rewritten in place by its only reader
         const float gy = s_gt[g * 5 + 0] / rate, gx = s_gt[g * 5 + 1] / rate;
         const float gh = s_gt[g * 5 + 2] / rate, gw = s_gt[g * 5 + 3] / rate;
         const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
         const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
         s_gt[g * 5 + 0] = y1; s_gt[g * 5 + 1] = x1; s_gt[g * 5 + 2] = y2; s_gt[g * 5 + 3] = x2;
-        s_gt[g * 5 + 4] = (y2 - y1) * (x2 - x1);
+        const float area = (y2 - y1) * (x2 - x1);
+        s_gt[g * 5 + 4] = area;
+        if (!EXACT_MAX) {
+            const float v[5] = {y1, x1, y2, x2, area};
+            float *slot = s_pair + (g >> 1) * kPairStride + (g & 1);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                slot[2 * k] = v[k];
+                if (g == G - 1 && (g & 1) == 0) slot[2 * k + 1] = v[k];    // odd count: the last row twice
+                in_bounds &= fabsf(v[k]) < kLossFastBound ? 1 : 0;
+            }
+        }
         const int cy = (int)floorf(gy), cx = (int)floorf(gx);
         if (cy >= 0 && cy < H && cx >= 0 && cx < W) {
             const int cell = cy * W + cx;
             atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
         }
     }
-    __syncthreads();
+    const bool gt_in_bounds = __syncthreads_and(in_bounds) != 0;
 
     // The objectness logit is asked for here, after the ground-truth round trip (memory loads
     // return in issue order: an earlier request would hold that round trip back), and is not
@@ -165,7 +182,9 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             // YOLOv3.py:246-257: L = a_yx - a_hw/2 and U = a_yx + a_hw/2 are then used
             // as (centre, size): corners L - U/2 and L + U/2.
             const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
-            const float ah = sc.prior_hw[pi][0], aw = sc.prior_hw[pi][1];
+            float ah = 0.0f, aw = 0.0f;                   // uniform walk: scalar reads of the parameter block
+            for (int q = 0; q < P; ++q)
+                if (pi == (uint32_t)q) { ah = sc.prior_hw[q][0]; aw = sc.prior_hw[q][1]; }
             const float ly = ay - ah / 2.0f, lx = ax - aw / 2.0f;
             const float uy = ay + ah / 2.0f, ux = ax + aw / 2.0f;
             const float by1 = ly - uy / 2.0f, bx1 = lx - ux / 2.0f;
@@ -187,30 +206,42 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                 if (any_nan) m = __builtin_nanf("");
                 counted = m <= p.ignore_thr;
             } else {
-                // Branch-free pass.  With d = sign(uni) * inter - thr * |uni| (one rounding) and the
-                // margin m = 2^-20 * max(1, thr) * |uni| + 2^-100:  d > m implies RN(inter / uni) > thr
-                // and d < -m implies the opposite (the roundings involved stay below 2^-22 relative;
-                // the constant keeps tiny unions out).  Anything else (inside the margin, zero or
-                // non-finite operands: the comparisons are then both false) clears `decided`.
+                // Division-free pass, two ground-truth rows per step in packed arithmetic.  With
+                // d = sign(uni) * inter - thr * |uni| (one rounding) and the margin
+                // m = 2^-20 * max(1, thr) * |uni| + 2^-100:  d > m implies RN(inter / uni) > thr and
+                // d < -m implies the opposite (the roundings involved stay below 2^-22 relative; the
+                // constant keeps tiny unions out).  e = d - m and h = max(d - m, -d - m) are folded
+                // into a running maximum and minimum: some e > 0 means "masked", every h > 0 means
+                // every pair was decided.  That bookkeeping needs NaN-free values, which the bounds
+                // on the operands guarantee (no product can overflow); otherwise, and for a pair
+                // inside the margin, the exact walk below decides.
                 const float thr = p.ignore_thr;
+                const bool fast = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f &&
+                                  fabsf(ah) < kLossFastBound && fabsf(aw) < kLossFastBound;
                 const float mfac = 0x1p-20f * fmaxf(1.0f, thr);
-                bool hit = false, decided = thr >= 0.0f;
-                for (int g = 0; g < G; ++g) {
-                    const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
-                    const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
-                    const float garea = s_gt[g * 5 + 4];
-                    const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
-                    const float uni = (aarea + garea) - inter;
-                    const float au = fabsf(uni);
-                    const float si = __uint_as_float(__float_as_uint(inter) ^ (__float_as_uint(uni) & 0x80000000u));
-                    const float d = __builtin_fmaf(-thr, au, si);
-                    const float m = __builtin_fmaf(mfac, au, 0x1p-100f);
-                    const bool above = d > m, below = d < -m;
-                    hit |= above;
-                    decided &= above | below;
+                float e_max = -INFINITY, h_min = fast ? INFINITY : -INFINITY;
+                const int pairs = fast ? (G + 1) >> 1 : 0;
+                const f2 nthr = {-thr, -thr}, mf = {mfac, mfac}, tiny = {0x1p-100f, 0x1p-100f};
+                const f2 aa = {aarea, aarea};
+                for (int j = 0; j < pairs; ++j) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'
+                    const float4 hi = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride + 4);  // y2 y2' x2 x2'
+                    const float2 ar = *reinterpret_cast<const float2 *>(s_pair + j * kPairStride + 8);
+                    const f2 dy = f2{vmin(hi.x, by2), vmin(hi.y, by2)} - f2{vmax(lo.x, by1), vmax(lo.y, by1)};
+                    const f2 dx = f2{vmin(hi.z, bx2), vmin(hi.w, bx2)} - f2{vmax(lo.z, bx1), vmax(lo.w, bx1)};
+                    const f2 inter = dy * dx;
+                    const f2 uni = (aa + f2{ar.x, ar.y}) - inter;
+                    const f2 au = {fabsf(uni.x), fabsf(uni.y)};
+                    const f2 si = {__uint_as_float(__float_as_uint(inter.x) ^ (__float_as_uint(uni.x) & 0x80000000u)),
+                                   __uint_as_float(__float_as_uint(inter.y) ^ (__float_as_uint(uni.y) & 0x80000000u))};
+                    const f2 d = __builtin_elementwise_fma(nthr, au, si);
+                    const f2 m = __builtin_elementwise_fma(mf, au, tiny);
+                    const f2 e = d - m, f = -d - m;
+                    e_max = fmaxf(e_max, fmaxf(e.x, e.y));
+                    h_min = fminf(h_min, fminf(fmaxf(e.x, f.x), fmaxf(e.y, f.y)));
                 }
-                int masked = hit ? 1 : 0;
-                const bool recheck = !decided;
+                int masked = e_max > 0.0f ? 1 : 0;
+                const bool recheck = !(h_min > 0.0f);
                 if (recheck) {                    // rare: the exact walk decides
                     masked = 0;
                     for (int g = 0; g < G; ++g) {
@@ -252,6 +283,7 @@ struct GtAssign {
     uint32_t row;        // box row inside the scale: (cy * W + cx) * P + p
     int label;
     float gy, gx, gh, gw;   // the GT in grid units of scale s
+    float prior_h, prior_w; // the assigned prior
     bool inside;         // the centre's cell lies inside the grid
 };
 
@@ -298,6 +330,9 @@ __device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *
     int psel = 0;
 #pragma unroll
     for (int s = 0; s < YH_MAX_SCALES; ++s) if (s == ssel) psel = best_p[s];
+    // wave-uniform by construction; saying so keeps the parameter-block reads below scalar
+    ssel = __builtin_amdgcn_readfirstlane(ssel);
+    psel = __builtin_amdgcn_readfirstlane(psel);
     const LossScale &sc = p.sc[ssel];
     const float rate = sc.gt_rate;
     a.s = ssel; a.p = psel;
@@ -305,6 +340,7 @@ __device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *
     const int cy = (int)floorf(a.gy), cx = (int)floorf(a.gx);
     a.inside = cy >= 0 && cy < sc.H && cx >= 0 && cx < sc.W;
     a.row = a.inside ? (uint32_t)((cy * sc.W + cx) * P + psel) : 0u;
+    a.prior_h = sc.prior_hw[psel][0]; a.prior_w = sc.prior_hw[psel][1];
     return a;
 }
 
@@ -339,10 +375,10 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
                 } else if (k == C + 1) {
                     coord += sigmoid_ce(v, a.gx - floorf(a.gx));
                 } else if (k == C + 2) {
-                    const float d = v - logf(a.gh / sc.prior_hw[a.p][0]);
+                    const float d = v - logf(a.gh / a.prior_h);
                     coord += 0.5f * (d * d);
                 } else if (k == C + 3) {
-                    const float d = v - logf(a.gw / sc.prior_hw[a.p][1]);
+                    const float d = v - logf(a.gw / a.prior_w);
                     coord += 0.5f * (d * d);
                 } else {
                     obj += sigmoid_ce(v, 1.0f);
@@ -382,39 +418,39 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
 
 // ---------------------------------------------------------------- finalize
 // One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
-// the batch sum.  A wavefront per image: the lanes fetch the image's partial sums
-// together and add them up in double in a fixed tree, so the result does not
-// depend on scheduling.
+// the batch sum.  Sixteen lanes per image (64 images at a time): they fetch the
+// image's partial sums together and add them up in double in a fixed tree, so the
+// result does not depend on scheduling.
 constexpr int kFinalizeThreads = 1024;
+constexpr int kFinalizeLanes = 16;
+constexpr int kFinalizeGroups = kFinalizeThreads / kFinalizeLanes;
 
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ double group_sum(double v)
 {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    for (int d = kFinalizeLanes / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
 
 __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
 {
-    __shared__ double s_sum[kFinalizeThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double local = 0.0;                                        // lane 0 of each wave: its images' losses
-    for (int b = wave; b < p.B; b += kFinalizeThreads / 64) {
+    __shared__ double s_sum[kFinalizeGroups];
+    const int tid = threadIdx.x, gl = tid & (kFinalizeLanes - 1), grp = tid / kFinalizeLanes;
+    double local = 0.0;                                        // lane 0 of each group: its images' losses
+    for (int b = grp; b < p.B; b += kFinalizeGroups) {
         double coord = 0.0, cls = 0.0, obj = 0.0, noobj = 0.0;
+        const float gf = p.normalize ? (float)p.gcount[b] : 1.0f;
         const float *pp = p.pos_partial + (long long)b * p.pos_blocks * 3;
-        for (int i = lane; i < p.pos_blocks; i += 64) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
+        for (int i = gl; i < p.pos_blocks; i += kFinalizeLanes) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
         const float *np_ = p.neg_partial + (long long)b * p.blocks_per_img;
-        for (int i = lane; i < p.blocks_per_img; i += 64) noobj += np_[i];
-        coord = wave_sum(coord); cls = wave_sum(cls); obj = wave_sum(obj); noobj = wave_sum(noobj);
+        for (int i = gl; i < p.blocks_per_img; i += kFinalizeLanes) noobj += np_[i];
+        coord = group_sum(coord); cls = group_sum(cls); obj = group_sum(obj); noobj = group_sum(noobj);
         const float fc = (float)coord, fk = (float)cls, fo = (float)obj, fn = (float)noobj;
         float pos = (p.w_coord * fc + p.w_class * fk) + p.w_obj * fo;
         float neg = p.w_noobj * fn;
-        if (p.normalize) {
-            const float gf = (float)p.gcount[b];
-            pos = pos / gf; neg = neg / gf;
-        }
+        if (p.normalize) { pos = pos / gf; neg = neg / gf; }
         const float li = pos + neg;
-        if (lane == 0) {
+        if (gl == 0) {
             p.loss_per_image[b] = li;
             if (p.loss_parts) {
                 p.loss_parts[b * 4 + 0] = fc; p.loss_parts[b * 4 + 1] = fk;
@@ -423,11 +459,11 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossPa
             local += (double)li;
         }
     }
-    if (lane == 0) s_sum[wave] = local;
+    if (gl == 0) s_sum[grp] = local;
     __syncthreads();
     if (tid == 0 && p.loss_sum) {
         double acc = 0.0;
-        for (int w = 0; w < kFinalizeThreads / 64; ++w) acc += s_sum[w];
+        for (int g = 0; g < kFinalizeGroups; ++g) acc += s_sum[g];
         *p.loss_sum = (float)acc;
     }
 }
@@ -529,8 +565,8 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams 
         if (k < C) d = p.w_class * (sigmoidf(v) - (k == a.label ? 1.0f : 0.0f));
         else if (k == C) d = p.w_coord * (sigmoidf(v) - (a.gy - floorf(a.gy)));
         else if (k == C + 1) d = p.w_coord * (sigmoidf(v) - (a.gx - floorf(a.gx)));
-        else if (k == C + 2) d = p.w_coord * (v - logf(a.gh / sc.prior_hw[a.p][0]));
-        else if (k == C + 3) d = p.w_coord * (v - logf(a.gw / sc.prior_hw[a.p][1]));
+        else if (k == C + 2) d = p.w_coord * (v - logf(a.gh / a.prior_h));
+        else if (k == C + 3) d = p.w_coord * (v - logf(a.gw / a.prior_w));
         else d = p.w_obj * (sigmoidf(v) - 1.0f);
         atomicAdd(&grow[k], d * w);
     }
@@ -554,7 +590,8 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
         if (w > occ_words) occ_words = w;
     }
-    const size_t lds = (size_t)p.pad * 5 * sizeof(float) + (size_t)occ_words * sizeof(uint32_t);
+    const size_t lds = (size_t)((p.pad + 1) / 2) * kPairStride * sizeof(float) + (size_t)p.pad * 5 * sizeof(float) +
+                       (size_t)occ_words * sizeof(uint32_t);
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
     if (p.iou_max) hipLaunchKernelGGL(k_loss_main<true>, grid, dim3(kLossNegThreads), lds, stm, p);
     else hipLaunchKernelGGL(k_loss_main<false>, grid, dim3(kLossNegThreads), lds, stm, p);

@@ -4,10 +4,11 @@ ignore threshold 0.6, no division of the loss by the ground-truth count.
 
 Head tensors come from config['head_provider'] (callable(images) -> pred,
 NHWC float32 CUDA tensor [B, H, W, len(priors)*(num_classes+5)]) or, without a
-provider, `images` is that tensor already.  data_provider['train_generator'] =
-(initializer callable or None, iterator of (images_or_head, ground_truth)).
-train_one_epoch evaluates the loss only (no optimiser step: the convolution
-stack is outside this path).
+provider, `images` is either that tensor already or a batch of images, for which
+the reference's own convolution stack (backbone.Darknet19Head) is built on first
+use.  data_provider['train_generator'] = (initializer callable or None, iterator
+of (images_or_head, ground_truth)).  train_one_epoch takes an optimisation step
+through the fused loss backward when the head tensor carries an autograd graph.
 """
 import os
 import sys
@@ -86,7 +87,22 @@ class YOLOv2:
         gn[:, :4] = gn[:, :4] / np.float32(downsampling_rate)
         return gn[..., :2], gn[..., 2:4], gn[..., 4].astype(np.int32)
 
+    def _build_network(self):
+        """_build_graph's convolution stack (YOLOv2.py:75-93): built on first use, when
+        images rather than a head tensor arrive and no provider was configured."""
+        from .backbone import Darknet19Head
+        net = Darknet19Head(self.num_classes, self.num_priors, self.data_format, self.weight_decay)
+        return net.to(torch.device('cuda', torch.cuda.current_device()))
+
+    def _is_image_batch(self, x):
+        shape = getattr(x, 'shape', None)
+        if shape is None or len(shape) != 4:
+            return False
+        return shape[3 if self.data_format == 'channels_last' else 1] == 3      # final_units is never 3
+
     def _head_from(self, images):
+        if self.head_provider is None and self._is_image_batch(images):
+            self.head_provider = self._build_network()
         pred = self.head_provider(images) if self.head_provider is not None else images
         if isinstance(pred, (list, tuple)):
             if len(pred) != 1:

@@ -3,9 +3,10 @@ detection-head path.
 
 Kept from the reference: constructor signature and config / data_provider keys,
 train_one_epoch(lr), test_one_image(images), save_weight / load_weight /
-load_pretraining_weight, _get_priors and _get_normlized_gn.  The backbone and
-head convolutions are outside this path, so the head tensors come from a
-pluggable provider:
+load_pretraining_weight, _get_priors and _get_normlized_gn.  The head tensors
+come from a pluggable provider; when none is configured and a batch of images
+arrives, the reference's own convolution stack (backbone.Darknet53Heads) is
+built and used:
 
   * config['head_provider'] (optional): callable(images) -> [pred1, pred2,
     pred3], NHWC float32 CUDA tensors [B, H, W, num_priors*(num_classes+5)]
@@ -17,8 +18,9 @@ pluggable provider:
     (images_or_heads, ground_truth[B, pad, 5]) batches; they stand where the
     reference has a tf.data initializer op and iterator.
 
-train_one_epoch evaluates the loss only; the optimiser step belongs to the
-convolution stack and is not part of this path.
+train_one_epoch takes an optimisation step through the fused loss backward
+whenever the head tensors carry an autograd graph (the provider's zero_grad /
+step(lr) are the optimiser); with plain tensors it evaluates the loss only.
 """
 import datetime
 import os
@@ -111,7 +113,16 @@ class YOLOv3:
         gn = gt[:slice_index] / np.array([downsampling_rate] * 4 + [1], dtype=np.float32).reshape(1, 5)
         return gn[..., :2], gn[..., 2:4], gn[..., 4].astype(np.int32)
 
+    def _build_network(self):
+        """_build_graph's convolution stack (YOLOv3.py:81-91): built on first use, when
+        images rather than head tensors arrive and no provider was configured."""
+        from .backbone import Darknet53Heads
+        net = Darknet53Heads(self.num_classes, self.num_priors, self.data_format, self.weight_decay)
+        return net.to(torch.device('cuda', torch.cuda.current_device()))
+
     def _heads_from(self, images):
+        if self.head_provider is None and not isinstance(images, (list, tuple)):
+            self.head_provider = self._build_network()
         preds = self.head_provider(images) if self.head_provider is not None else images
         if not isinstance(preds, (list, tuple)) or len(preds) != 3:
             raise ValueError('three head tensors (pred1, pred2, pred3) are required')

@@ -68,6 +68,19 @@ def decode_ground_truth(block):
     return boxes.astype(np.float32), rows[:, 4].astype(np.int32)
 
 
+def draw_detections(image, scores, bbox, class_id, names=ids_to_classname, color=(255, 0, 0)):
+    """The reference's (commented-out) plotting snippet, testYOLOv3.py:81-97: a rectangle
+    per detection from (x1, y1) to (x2, y2) and the caption 'name score' at its top-left
+    corner.  image: HWC array, 0..255.  Returns a PIL image."""
+    from PIL import Image, ImageDraw
+    canvas = Image.fromarray(np.clip(np.asarray(image), 0, 255).astype(np.uint8))
+    draw = ImageDraw.Draw(canvas)
+    for rec in detections_to_records(scores, bbox, class_id, names):
+        draw.rectangle([rec['x1'], rec['y1'], max(rec['x1'], rec['x2']), max(rec['y1'], rec['y2'])], outline=color)
+        draw.text((rec['x1'], rec['y1']), '%s %.3f' % (rec['name'], rec['score']), fill=color)
+    return canvas
+
+
 def detections_to_records(scores, bbox, class_id, names=ids_to_classname):
     """test_one_image's result as a list of dicts (name, score, y1, x1, y2, x2), the
     values the reference's plotting snippet reads (testYOLOv3.py:81-97)."""

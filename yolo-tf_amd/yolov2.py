@@ -152,8 +152,11 @@ class YOLOv2:
         num_iters = self.num_train // self.batch_size
         for i in range(num_iters):
             images, ground_truth = next(self.train_iterator)
-            self.ground_truth = ground_truth
             head = self._head_from(images)
+            if not isinstance(ground_truth, torch.Tensor):          # e.g. NumPy batches of records.get_generator
+                ground_truth = torch.as_tensor(np.asarray(ground_truth, dtype=np.float32))
+            ground_truth = ground_truth.to(head.device)
+            self.ground_truth = ground_truth
             if head.requires_grad:
                 total_loss = self._train_step(head, ground_truth, lr)
             else:                                            # a head without a graph: the loss value only

@@ -179,8 +179,11 @@ class YOLOv3:
         num_iters = self.num_train // self.batch_size
         for i in range(num_iters):
             images, ground_truth = next(self.train_iterator)
-            self.ground_truth = ground_truth
             heads = self._heads_from(images)
+            if not isinstance(ground_truth, torch.Tensor):          # e.g. NumPy batches of records.get_generator
+                ground_truth = torch.as_tensor(np.asarray(ground_truth, dtype=np.float32))
+            ground_truth = ground_truth.to(heads[0].device)
+            self.ground_truth = ground_truth
             if any(h.requires_grad for h in heads):
                 total_loss = self._train_step(heads, ground_truth, lr, 0.5)
             else:                                            # heads without a graph: the loss value only

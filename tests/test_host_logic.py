@@ -101,6 +101,18 @@ def test_two_rank_gloo_loss_mean_matches_full_batch():
     assert r.stdout.count('GLOO_OK') == 2, r.stdout + r.stderr
 
 
+def test_two_rank_gloo_optimizer_step():
+    """world_size 2 on CPU (gloo): the convolution stacks' step(lr) all-reduces the
+    gradients in one flat bucket, so both ranks take the step of the summed gradient."""
+    script = os.path.join(ROOT, 'tests', 'gloo_step_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29733', script],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('GLOO_STEP_OK') == 2, r.stdout + r.stderr
+
+
 def test_ground_truth_wire_format_round_trip():
     """utils/image_augmentor.py:205-244: centre filter, clamp, (yc, xc, h, w, class), -1 padding."""
     boxes = [[10, 20, 50, 80], [-30, -30, 10, 10], [400, 400, 430, 440], [390, 10, 430, 60]]

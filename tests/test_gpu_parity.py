@@ -283,6 +283,26 @@ def test_candidate_overflow_is_reported_and_rerun(gpu, c_oracle):
     cases.same_detections(res.per_image(), want)
 
 
+@pytest.mark.parametrize('cap', [40000, 9000])
+def test_long_candidate_lists_are_binned_in_slices(gpu, c_oracle, cap):
+    """About 16000 candidates per image: the class binning runs over several slices of the
+    list (capacity beyond one slice), twice on the same workspace; with a capacity below
+    the count the overflow is flagged and the rerun gives the full answer."""
+    case = cases.stress(grid=40, P=10, C=80)
+    heads = case.heads(61, 2, **y.synth.STRESS)
+    dheads = to_dev(heads, gpu)
+    hd = case.head_obj()
+    boxes, conf = hd.decode(dheads)
+    want = c_oracle.nms(boxes.cpu().numpy(), conf.cpu().numpy(), 0.001, 0.5, 100)
+    assert (conf.cpu().numpy() >= 0.001).sum(axis=(1, 2)).min() > 9000
+    for _ in range(2):
+        res = hd.detect(dheads, 0.001, 0.5, 100, max_candidates=cap, want_class_candidates=True)
+        assert res.overflowed() == (cap == 9000)
+        cases.same_detections(res.per_image(), want)
+    staged = hd.nms(boxes, conf, 0.001, 0.5, 100, max_candidates=cap)
+    cases.same_detections(staged.per_image(), want)
+
+
 def test_long_segment_sorts_in_global_memory(gpu, c_oracle):
     """One class takes every box: a 4000-candidate segment (beyond the LDS sort)."""
     case = cases.stress(grid=20, P=10, C=3)

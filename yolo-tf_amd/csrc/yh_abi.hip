@@ -90,7 +90,7 @@ float prefilter_logit(float thr)
 struct DetectWs {
     unsigned long long *cand, *seg_keys, *ukeys;
     float *boxes, *cand_box, *uboxes;
-    int32_t *img_count, *seg_off, *seg_cnt, *kept_cnt, *kept_row;
+    int32_t *img_count, *seg_off, *seg_cnt, *class_hist, *class_cursor, *kept_cnt, *kept_row;
     float *kept_score;
     size_t bytes;
 };
@@ -114,6 +114,7 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     w.uboxes = reinterpret_cast<float *>(p + o_ub);
     const size_t o_img = take((size_t)B * 4);
     const size_t o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
+    const size_t o_hist = take((size_t)B * C * 4), o_cur = take((size_t)B * C * 4);
     const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
     w.cand = reinterpret_cast<unsigned long long *>(p + o_cand);
     w.seg_keys = reinterpret_cast<unsigned long long *>(p + o_seg);
@@ -121,6 +122,8 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     w.img_count = reinterpret_cast<int32_t *>(p + o_img);
     w.seg_off = reinterpret_cast<int32_t *>(p + o_off);
     w.seg_cnt = reinterpret_cast<int32_t *>(p + o_cnt);
+    w.class_hist = reinterpret_cast<int32_t *>(p + o_hist);
+    w.class_cursor = reinterpret_cast<int32_t *>(p + o_cur);
     w.kept_cnt = reinterpret_cast<int32_t *>(p + o_kc);
     w.kept_row = reinterpret_cast<int32_t *>(p + o_kr);
     w.kept_score = reinterpret_cast<float *>(p + o_ks);
@@ -351,6 +354,7 @@ static yh::NmsParams make_nms_params(const DetectWs &w, int32_t B, int32_t C, in
     q.B = B; q.C = C; q.N = N; q.cand_cap = max_cand; q.max_boxes = max_boxes; q.iou_thr = iou_thr;
     q.cand = w.cand; q.seg_keys = w.seg_keys; q.img_count = w.img_count;
     q.seg_off = w.seg_off; q.seg_cnt = w.seg_cnt; q.kept_cnt = w.kept_cnt;
+    q.class_hist = w.class_hist; q.class_cursor = w.class_cursor;
     q.kept_row = w.kept_row; q.kept_score = w.kept_score; q.boxes = boxes;
     q.out_count = out_count; q.out_scores = out_scores; q.out_boxes = out_boxes;
     q.out_class = out_class; q.out_index = out_index; q.out_class_candidates = out_class_candidates;

@@ -114,6 +114,8 @@ struct NmsParams {
     int32_t *img_count;                // [B]; zeroed again once consumed
     int32_t *seg_off;                  // [B][C]
     int32_t *seg_cnt;                  // [B][C]
+    int32_t *class_hist;               // [B][C] sliced binning: class counts; zero between calls
+    int32_t *class_cursor;             // [B][C] sliced binning: reserved entries per class; zero between calls
     int32_t *kept_cnt;                 // [B][C]
     int32_t *kept_row;                 // [B][C][max_boxes]
     float *kept_score;                 // [B][C][max_boxes]

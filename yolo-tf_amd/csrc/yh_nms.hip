@@ -88,6 +88,86 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(const NmsParams p)
     }
 }
 
+// The same binning for long candidate lists, spread over kBinSlice-sized slices of an image's
+// list (one workgroup each) in two launches: k_bin_count adds the slices' class histograms
+// into class_hist; k_bin_scatter scans the image's histogram (every slice's workgroup does,
+// redundantly: C values), reserves its share of every class segment with one global atomic
+// per class it holds, and scatters its slice.  One workgroup per image walked the whole list
+// twice with every thread contending for the C counters in LDS.  For candidates that live in
+// the list only (no private slots, no slot-indexed boxes).  class_hist, class_cursor and
+// img_count are zero between calls: k_sort_nms clears them.
+constexpr int kBinSlice = 8192;
+constexpr int kBinSliceThreads = 256;
+
+__device__ __forceinline__ void slice_range(const NmsParams &p, int b, int sub, int &begin, int &end, int &raw)
+{
+    raw = p.img_count[b];
+    const int nl = raw < p.cand_cap ? raw : p.cand_cap;
+    begin = sub * kBinSlice;
+    end = begin + kBinSlice < nl ? begin + kBinSlice : nl;
+}
+
+__global__ __launch_bounds__(kBinSliceThreads) void k_bin_count(const NmsParams p, int slices)
+{
+    __shared__ int s_h[YH_MAX_CLASSES];
+    const int b = blockIdx.x / slices, sub = blockIdx.x - b * slices, tid = threadIdx.x, C = p.C;
+    int begin, end, raw;
+    slice_range(p, b, sub, begin, end, raw);
+    if (begin >= end) return;
+    for (int c = tid; c < C; c += kBinSliceThreads) s_h[c] = 0;
+    __syncthreads();
+    const unsigned long long *cand = p.cand + (long long)b * p.cand_cap;
+    for (int i = begin + tid; i < end; i += kBinSliceThreads) atomicAdd(&s_h[key_class(cand[i])], 1);
+    __syncthreads();
+    for (int c = tid; c < C; c += kBinSliceThreads)
+        if (s_h[c]) atomicAdd(&p.class_hist[b * C + c], s_h[c]);
+}
+
+__global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParams p, int slices)
+{
+    __shared__ int s_cur[YH_MAX_CLASSES];    // histogram, then each segment's write cursor for this slice
+    __shared__ int s_end[YH_MAX_CLASSES];    // count, then each segment's end
+    __shared__ int s_mine[YH_MAX_CLASSES];   // this slice's histogram
+    __shared__ int s_wave[kBinSliceThreads / 64];
+    const int b = blockIdx.x / slices, sub = blockIdx.x - b * slices, tid = threadIdx.x, C = p.C, cap = p.cand_cap;
+    int begin, end, raw;
+    slice_range(p, b, sub, begin, end, raw);
+    if (sub > 0 && begin >= end) return;
+    for (int c = tid; c < C; c += kBinSliceThreads) { s_cur[c] = p.class_hist[b * C + c]; s_mine[c] = 0; }
+    __syncthreads();
+    for (int c = tid; c < C; c += kBinSliceThreads) s_end[c] = s_cur[c];
+    __syncthreads();
+    block_exclusive_scan<kBinSliceThreads, YH_MAX_CLASSES / kBinSliceThreads>(s_cur, C, s_wave);
+    const int found = s_cur[C - 1] + s_end[C - 1];
+    __syncthreads();
+    for (int c = tid; c < C; c += kBinSliceThreads) {
+        const int o = s_cur[c] < cap ? s_cur[c] : cap;
+        const int n = s_end[c] < cap - o ? s_end[c] : cap - o;
+        if (sub == 0) {
+            p.seg_off[b * C + c] = o;
+            p.seg_cnt[b * C + c] = n;
+            if (p.out_class_candidates) p.out_class_candidates[b * C + c] = n;
+        }
+        s_cur[c] = o;
+        s_end[c] = o + n;
+    }
+    if (sub == 0 && tid == 0) p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
+    __syncthreads();
+    const unsigned long long *cand = p.cand + (long long)b * cap;
+    for (int i = begin + tid; i < end; i += kBinSliceThreads) atomicAdd(&s_mine[key_class(cand[i])], 1);
+    __syncthreads();
+    for (int c = tid; c < C; c += kBinSliceThreads)
+        if (s_mine[c]) s_cur[c] += atomicAdd(&p.class_cursor[b * C + c], s_mine[c]);
+    __syncthreads();
+    unsigned long long *out = p.seg_keys + (long long)b * cap;
+    for (int i = begin + tid; i < end; i += kBinSliceThreads) {
+        const unsigned long long k = cand[i];
+        const int c = key_class(k);
+        const int pos = atomicAdd(&s_cur[c], 1);
+        if (pos < s_end[c]) out[pos] = k;
+    }
+}
+
 // One workgroup per (image, class) segment.
 __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
 {
@@ -96,6 +176,11 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int b = seg / p.C;
     const int cnt = p.seg_cnt[seg];
+    if (tid == 0) {                           // the binning's counters, clean for the next call
+        p.class_hist[seg] = 0;
+        p.class_cursor[seg] = 0;
+        if (seg == b * p.C) p.img_count[b] = 0;
+    }
     if (cnt == 0) {
         if (tid == 0) p.kept_cnt[seg] = 0;
         return;
@@ -191,8 +276,17 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
         hipLaunchKernelGGL(k_post, dim3(p.B), dim3(kPostThreads), lds, stm, p);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_bin, dim3(p.B), dim3(kBinThreads), 0, stm, p);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (p.upi == 0 && !p.boxes_fill && !p.cand_box && p.cand_cap > kBinSlice) {
+        const int slices = (p.cand_cap + kBinSlice - 1) / kBinSlice;
+        const dim3 grid((uint32_t)p.B * (uint32_t)slices);
+        hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinSliceThreads), 0, stm, p, slices);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinSliceThreads), 0, stm, p, slices);
+    } else {
+        hipLaunchKernelGGL(k_bin, dim3(p.B), dim3(kBinThreads), 0, stm, p);
+    }
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_sort_nms, dim3((uint32_t)p.B * (uint32_t)p.C), dim3(kSegThreads), 0, stm, p);
     e = hipGetLastError();

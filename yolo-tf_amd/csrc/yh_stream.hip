@@ -164,47 +164,45 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         } else {
             nrows = rows_t;
         }
-        // ---- B: class logits of those rows, spread over all lanes.  Two steps per chunk of
-        // kHitCap items: the cheap prefilter collects the items that pass, then the lanes take
-        // the collected items densely.  (Doing the exact test where an item is found leaves one
-        // or two lanes of a wavefront working while the others wait: with dense candidates
-        // that made the kernel compute-bound at a few percent lane utilisation.)
+        // ---- B: class logits of those rows, spread over all lanes, in two steps: the cheap
+        // prefilter collects the items that pass, then the lanes take the collected items
+        // densely.  (Doing the exact test where an item is found leaves one or two lanes of a
+        // wavefront working while the others wait: with dense candidates that made the kernel
+        // compute-bound at a few percent lane utilisation.)  An item that finds the list full
+        // is worked on where it was found.
         const int items = nrows * C;
-        for (int chunk0 = 0; chunk0 < items; chunk0 += kHitCap) {
-            const int chunk_end = chunk0 + kHitCap < items ? chunk0 + kHitCap : items;
-            for (int item = chunk0 + tid; item < chunk_end; item += kThreads) {
-                const int ri = (int)__umulhi((uint32_t)item, p.magic_c), c = item - ri * C;   // item < 2^13
-                const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
-                if (tile[rr * K + c] >= pf) st.hits[atomicAdd(&st.nhits, 1)] = (uint16_t)item;
-            }
-            __syncthreads();
-            const int nhits = st.nhits;
-            for (int h = tid; h < nhits; h += kThreads) {
-                const int item = st.hits[h];
-                const int ri = item / C, c = item - ri * C;
-                const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
-                const float *rp = tile + rr * K;
-                const float x = rp[c];
-                const uint32_t row = row_t + (uint32_t)rr;
-                const int n = (int)(sc.row_base + row);
-                if (MODE == kModeConf) {                      // the stream is the confidence matrix itself
-                    push_candidate(st, p, b, make_key(c, x, n));
-                } else {
-                    const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
-                    if (cf >= p.thr) {
-                        reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
-                            decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
-                        push_candidate(st, p, b, make_key(c, cf, n));
-                    }
+        auto exact = [&](int item) {
+            const int ri = item / C, c = item - ri * C;
+            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+            const float *rp = tile + rr * K;
+            const float x = rp[c];
+            const uint32_t row = row_t + (uint32_t)rr;
+            const int n = (int)(sc.row_base + row);
+            if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
+                push_candidate(st, p, b, make_key(c, x, n));
+            } else {
+                const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
+                if (cf >= p.thr) {
+                    reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
+                        decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
+                    push_candidate(st, p, b, make_key(c, cf, n));
                 }
             }
-            __syncthreads();
-            if (tid == 0) st.nhits = 0;
-            if (st.count >= kStage / 2) flush_candidates(st, p, b);   // uniform: count was read after a barrier
-            __syncthreads();
+        };
+        for (int item = tid; item < items; item += kThreads) {
+            const int ri = (int)__umulhi((uint32_t)item, p.magic_c), c = item - ri * C;   // item < 2^13
+            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+            if (tile[rr * K + c] >= pf) {
+                const int slot = atomicAdd(&st.nhits, 1);
+                if (slot < kHitCap) st.hits[slot] = (uint16_t)item;
+                else exact(item);
+            }
         }
         __syncthreads();
-        if (tid == 0) st.nrows = 0;
+        const int nhits = st.nhits < kHitCap ? st.nhits : kHitCap;
+        for (int h = tid; h < nhits; h += kThreads) exact(st.hits[h]);
+        __syncthreads();
+        if (tid == 0) { st.nrows = 0; st.nhits = 0; }
         if (st.count >= kStage / 2) flush_candidates(st, p, b);
     }
     __syncthreads();

@@ -90,7 +90,7 @@ struct StreamParams {
 
 hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t st);
 
-constexpr int kTileFloats = 8192;                   // LDS tile of the streaming pass: 32 KiB
+constexpr int kTileFloats = 5120;                   // LDS tile of the streaming pass: 20 KiB
 
 enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
 

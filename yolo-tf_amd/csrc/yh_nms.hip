@@ -225,19 +225,24 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     if (tid == 0) p.kept_cnt[seg] = kept;
 }
 
-// One workgroup per image: concatenate the classes' selections (YOLOv3.py:362-367).
-__global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p)
+// Concatenates the classes' selections of an image (YOLOv3.py:362-367).  `parts` workgroups
+// per image share the C * max_boxes slots (each scans the image's C counts itself): the walk
+// is a chain of dependent loads per slot, so it wants many lanes, not many iterations.
+constexpr int kFinSlots = 4 * kFinThreads;   // slots per workgroup
+
+__global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int parts)
 {
     __shared__ int s_off[YH_MAX_CLASSES];
     __shared__ int s_wave[kFinThreads / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, C = p.C, mb = p.max_boxes;
+    const int b = blockIdx.x / parts, part = blockIdx.x - b * parts, tid = threadIdx.x, C = p.C, mb = p.max_boxes;
     const int32_t *kept = p.kept_cnt + (long long)b * C;
     for (int c = tid; c < C; c += kFinThreads) s_off[c] = kept[c];
     __syncthreads();
     block_exclusive_scan<kFinThreads, YH_MAX_CLASSES / kFinThreads>(s_off, C, s_wave);
     const long long cap = (long long)C * mb;
     const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
-    for (long long e = tid; e < cap; e += kFinThreads) {
+    const long long e_end = (long long)(part + 1) * kFinSlots < cap ? (long long)(part + 1) * kFinSlots : cap;
+    for (long long e = (long long)part * kFinSlots + tid; e < e_end; e += kFinThreads) {
         const int c = (int)(e / mb), j = (int)(e - (long long)c * mb);
         if (j < kept[c]) {
             const long long src = ((long long)b * C + c) * mb + j;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p)
             p.out_index[dst] = n;
         }
     }
-    if (tid == 0) p.out_count[b] = s_off[C - 1] + kept[C - 1];
+    if (part == 0 && tid == 0) p.out_count[b] = s_off[C - 1] + kept[C - 1];
 }
 
 static bool single_launch_shape(const NmsParams &p)
@@ -291,7 +296,8 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     hipLaunchKernelGGL(k_sort_nms, dim3((uint32_t)p.B * (uint32_t)p.C), dim3(kSegThreads), 0, stm, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_finalize, dim3(p.B), dim3(kFinThreads), 0, stm, p);
+    const int parts = (int)(((long long)p.C * p.max_boxes + kFinSlots - 1) / kFinSlots);
+    hipLaunchKernelGGL(k_finalize, dim3((uint32_t)p.B * (uint32_t)parts), dim3(kFinThreads), 0, stm, p, parts);
     return hipGetLastError();
 }
 

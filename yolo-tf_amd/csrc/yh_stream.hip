@@ -30,7 +30,7 @@ namespace yh {
 
 constexpr int kThreads = 256;
 constexpr int kStage = 384;      // candidate keys staged per workgroup
-constexpr int kHitCap = 1024;    // class logits that passed the prefilter, collected before they are worked on
+constexpr int kHitCap = 896;     // class logits that passed the prefilter, collected before they are worked on
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;

@@ -168,11 +168,98 @@ __global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParam
     }
 }
 
-// One workgroup per (image, class) segment.
+// ---- k_sort_nms: one workgroup per (image, class) segment ------------------------------
+// The greedy walk rarely looks past the first few hundred candidates of a long segment, so a
+// segment that fits into LDS is not sorted whole: a radix selection on the score bits of the
+// keys (two 8-bit levels at most) picks a prefix of the score order that holds at least
+// `target` candidates, only that prefix is sorted, and the walk runs on it.  If the walk uses
+// the prefix up before max_boxes boxes are selected, the whole segment is sorted and walked
+// again: the result is that of the full sort in every case.
+constexpr int kSelMax = 1024;        // longest prefix sorted on its own
+
+// Bins of s_hist -> the first bin at which the running count reaches `target`; wave 0 only.
+// Returns the bin, its inclusive running count in *cum; `before` is added to the counts.
+__device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before, int target, int *cum)
+{
+    const int lane = threadIdx.x & 63;
+    int a[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = s_hist[4 * lane + k]; sum += a[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    int c = before + incl - sum, found = -1, at = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c += a[k];
+        if (found < 0 && c >= target) { found = 4 * lane + k; at = c; }
+    }
+    const unsigned long long m = __ballot(found >= 0);
+    if (m == 0ull) { *cum = before + __builtin_amdgcn_readlane(incl, 63); return 255; }
+    const int src = __ffsll((long long)m) - 1;
+    *cum = __builtin_amdgcn_readlane(at, src);
+    return __builtin_amdgcn_readlane(found, src);
+}
+
+// Block-wide.  s_keys[0..cnt) -> s_sel[0..n): the n smallest keys for some n in [target, kSelMax],
+// unordered; returns n, or 0 when no such prefix exists at the two levels' resolution.
+__device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, int target,
+                                    unsigned long long *s_sel, int *s_hist, int *s_ctl)
+{
+    const int tid = threadIdx.x;
+    constexpr int kShift1 = 44, kShift2 = 36;              // the top two bytes of the 32 score bits at [51:20]
+    s_hist[tid] = 0;                                        // kSegThreads == 256 bins
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kSegThreads) atomicAdd(&s_hist[(int)(s_keys[i] >> kShift1) & 0xFF], 1);
+    __syncthreads();
+    if (tid < 64) {
+        int cum;
+        const int d1 = first_bin_reaching(s_hist, 0, target, &cum);
+        if (tid == 0) { s_ctl[0] = d1; s_ctl[1] = cum; s_ctl[2] = cum - s_hist[d1]; s_ctl[3] = 0; }
+    }
+    __syncthreads();
+    const int d1 = s_ctl[0], cum1 = s_ctl[1], below = s_ctl[2];
+    int d2 = 255, n = cum1;
+    __syncthreads();
+    if (cum1 > kSelMax) {                                   // the boundary bin is too full: split it by the next byte
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < cnt; i += kSegThreads) {
+            const unsigned long long k = s_keys[i];
+            if (((int)(k >> kShift1) & 0xFF) == d1) atomicAdd(&s_hist[(int)(k >> kShift2) & 0xFF], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int cum;
+            const int d = first_bin_reaching(s_hist, below, target, &cum);
+            if (tid == 0) { s_ctl[0] = d; s_ctl[1] = cum; }
+        }
+        __syncthreads();
+        d2 = s_ctl[0];
+        n = s_ctl[1];
+        __syncthreads();
+        if (n > kSelMax) return 0;
+    }
+    for (int i = tid; i < cnt; i += kSegThreads) {
+        const unsigned long long k = s_keys[i];
+        const int b1 = (int)(k >> kShift1) & 0xFF, b2 = (int)(k >> kShift2) & 0xFF;
+        if (b1 < d1 || (b1 == d1 && b2 <= d2)) s_sel[atomicAdd(&s_ctl[3], 1)] = k;
+    }
+    __syncthreads();
+    return n;
+}
+
 __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
 {
     __shared__ unsigned long long s_keys[kSortLds];
-    __shared__ float s_kbox[YH_MAX_NMS_BOXES][5];
+    __shared__ unsigned long long s_sel[kSelMax];
+    extern __shared__ __align__(16) unsigned char s_dyn[];    // the selected boxes: max_boxes x 5 floats
+    float (*s_kbox)[5] = reinterpret_cast<float (*)[5]>(s_dyn);
+    __shared__ int s_hist[kSegThreads];
+    __shared__ int s_ctl[4];
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int b = seg / p.C;
     const int cnt = p.seg_cnt[seg];
@@ -186,42 +273,71 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         return;
     }
     unsigned long long *keys = p.seg_keys + (long long)b * p.cand_cap + p.seg_off[seg];
+    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+    auto walk = [&](const unsigned long long *sorted, int n) {          // wave 0
+        return wave_nms<false>(sorted, n, boxes4, nullptr, s_kbox, p.iou_thr, p.max_boxes,
+                               p.kept_row + (long long)seg * p.max_boxes,
+                               p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
+    };
 
     if (cnt <= 64) {
         // rank sort inside one wavefront; keys are unique
-        if (tid < 64) {
-            const unsigned long long key = tid < cnt ? keys[tid] : ~0ull;
-            const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
-            int rank = 0;
-            for (int j = 0; j < cnt; ++j) {
-                const unsigned long long kj =
-                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, j) << 32) |
-                    (uint32_t)__builtin_amdgcn_readlane(lo, j);
-                rank += kj < key ? 1 : 0;
-            }
-            if (tid < cnt) s_keys[rank] = key;
+        if (tid >= 64) return;
+        const unsigned long long key = tid < cnt ? keys[tid] : ~0ull;
+        const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const unsigned long long kj =
+                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, j) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane(lo, j);
+            rank += kj < key ? 1 : 0;
         }
-        __syncthreads();
-        if (tid < cnt) keys[tid] = s_keys[tid];
-    } else if (cnt <= kSortLds) {
-        int n2 = 128;
-        while (n2 < cnt) n2 <<= 1;
+        if (tid < cnt) s_keys[rank] = key;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int kept = walk(s_keys, cnt);
+        if (tid == 0) p.kept_cnt[seg] = kept;
+        return;
+    }
+    if (cnt <= kSortLds) {
         for (int i = tid; i < cnt; i += kSegThreads) s_keys[i] = keys[i];
         __syncthreads();
-        bitonic_sort<kSegThreads>(s_keys, cnt, n2);
-        for (int i = tid; i < cnt; i += kSegThreads) keys[i] = s_keys[i];
-    } else {
-        int n2 = kSortLds;
+        const int target = 2 * p.max_boxes > 256 ? 2 * p.max_boxes : 256;
+        if (cnt >= 2 * target && target <= kSelMax) {
+            const int n = select_prefix(s_keys, cnt, target, s_sel, s_hist, s_ctl);
+            if (n > 0) {
+                int n2 = 128;
+                while (n2 < n) n2 <<= 1;
+                bitonic_sort<kSegThreads>(s_sel, n, n2);
+                if (tid < 64) {
+                    const int kept = walk(s_sel, n);
+                    if (tid == 0) {
+                        const bool done = kept >= p.max_boxes || n == cnt;
+                        s_ctl[0] = done ? 1 : 0;
+                        if (done) p.kept_cnt[seg] = kept;
+                    }
+                }
+                __syncthreads();
+                if (s_ctl[0]) return;
+                __syncthreads();
+            }
+        }
+        int n2 = 128;
         while (n2 < cnt) n2 <<= 1;
-        __syncthreads();
-        bitonic_sort<kSegThreads>(keys, cnt, n2);
+        bitonic_sort<kSegThreads>(s_keys, cnt, n2);
+        if (tid >= 64) return;
+        const int kept = walk(s_keys, cnt);
+        if (tid == 0) p.kept_cnt[seg] = kept;
+        return;
     }
+    int n2 = kSortLds;
+    while (n2 < cnt) n2 <<= 1;
+    __syncthreads();
+    bitonic_sort<kSegThreads>(keys, cnt, n2);
     __syncthreads();          // sorted keys in global memory, visible to wave 0
     if (tid >= 64) return;
-    const int kept = wave_nms<false>(keys, cnt, reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N,
-                                     nullptr, s_kbox, p.iou_thr, p.max_boxes,
-                                     p.kept_row + (long long)seg * p.max_boxes,
-                                     p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
+    const int kept = walk(keys, cnt);
     if (tid == 0) p.kept_cnt[seg] = kept;
 }
 
@@ -293,7 +409,8 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sort_nms, dim3((uint32_t)p.B * (uint32_t)p.C), dim3(kSegThreads), 0, stm, p);
+    hipLaunchKernelGGL(k_sort_nms, dim3((uint32_t)p.B * (uint32_t)p.C), dim3(kSegThreads),
+                       (size_t)p.max_boxes * 5 * sizeof(float), stm, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int parts = (int)(((long long)p.C * p.max_boxes + kFinSlots - 1) / kFinSlots);

@@ -50,10 +50,10 @@ template <int THREADS>
 __device__ inline void bitonic_sort(unsigned long long *a, int cnt, int n2)
 {
     const int tid = threadIdx.x;
-    for (int k = 2; k <= n2; k <<= 1) {
+    for (int k = 2, lg = 0; k <= n2; k <<= 1, ++lg) {        // lg = log2(k / 2): every divisor is a power of two
         const int half = k >> 1;
         for (int t = tid; t < (n2 >> 1); t += THREADS) {
-            const int blk = t / half, off = t - blk * half;
+            const int blk = t >> lg, off = t & (half - 1);
             const int i = blk * k + off, l = blk * k + (k - 1 - off);
             if (l < cnt) {
                 const unsigned long long x = a[i], y = a[l];
@@ -61,9 +61,9 @@ __device__ inline void bitonic_sort(unsigned long long *a, int cnt, int n2)
             }
         }
         __syncthreads();
-        for (int j = half >> 1; j >= 1; j >>= 1) {
+        for (int j = half >> 1, lj = lg - 1; j >= 1; j >>= 1, --lj) {
             for (int t = tid; t < (n2 >> 1); t += THREADS) {
-                const int i = (t / j) * 2 * j + (t % j), l = i + j;
+                const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 if (l < cnt) {
                     const unsigned long long x = a[i], y = a[l];
                     if (x > y) { a[i] = y; a[l] = x; }
@@ -79,10 +79,10 @@ template <int THREADS>
 __device__ inline void bitonic_sort_kv(unsigned long long *a, float4 *v, int cnt, int n2)
 {
     const int tid = threadIdx.x;
-    for (int k = 2; k <= n2; k <<= 1) {
+    for (int k = 2, lg = 0; k <= n2; k <<= 1, ++lg) {        // lg = log2(k / 2): every divisor is a power of two
         const int half = k >> 1;
         for (int t = tid; t < (n2 >> 1); t += THREADS) {
-            const int blk = t / half, off = t - blk * half;
+            const int blk = t >> lg, off = t & (half - 1);
             const int i = blk * k + off, l = blk * k + (k - 1 - off);
             if (l < cnt) {
                 const unsigned long long x = a[i], y = a[l];
@@ -90,9 +90,9 @@ __device__ inline void bitonic_sort_kv(unsigned long long *a, float4 *v, int cnt
             }
         }
         __syncthreads();
-        for (int j = half >> 1; j >= 1; j >>= 1) {
+        for (int j = half >> 1, lj = lg - 1; j >= 1; j >>= 1, --lj) {
             for (int t = tid; t < (n2 >> 1); t += THREADS) {
-                const int i = (t / j) * 2 * j + (t % j), l = i + j;
+                const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 if (l < cnt) {
                     const unsigned long long x = a[i], y = a[l];
                     if (x > y) { a[i] = y; a[l] = x; const float4 tv = v[i]; v[i] = v[l]; v[l] = tv; }

@@ -226,14 +226,23 @@ def test_candidates_then_select_calls(gpu):
 
 
 def test_streaming_variants_agree(gpu, monkeypatch):
-    """The wave-private streaming kernel (4 and 8 KiB tiles, 2..4 buffers, few and many
-    work units) and the workgroup-tile kernel find the same candidates."""
+    """The objectness-first kernel (the default; one to several steps per work unit), the
+    wave-private streaming kernel (4 and 8 KiB tiles, 2..4 buffers, few and many work units)
+    and the workgroup-tile kernel find the same candidates."""
     case = cases.v3(size=160)
     heads = case.heads(77, 3, obj_mean=-1.0)
     dheads = to_dev(heads, gpu)
     ref = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
     want, want_cc = ref.per_image(), ref.class_candidates.clone()
     assert int(ref.count.sum()) > 0
+    for steps in ('1', '3', '50'):
+        monkeypatch.setenv('YH_ROW_STEPS', steps)
+        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+        assert not got.overflowed()
+        cases.same_detections(got.per_image(), want)
+        assert torch.equal(got.class_candidates, want_cc)
+    monkeypatch.delenv('YH_ROW_STEPS')
+    monkeypatch.setenv('YH_DETECT_KERNEL', '2')
     for ni, nbuf, units in (('8', '3', '8192'), ('8', '2', '64'), ('4', '2', '300'), ('4', '3', '7'),
                             ('4', '4', '100000'), ('1', '3', '8192')):
         monkeypatch.setenv('YH_STREAM_NI', ni)

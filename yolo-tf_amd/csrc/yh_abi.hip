@@ -167,10 +167,42 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
     // beyond the single-launch select stage announces a dense candidate set (low thresholds): there
     // the workgroup-tile variant, which appends 512 candidates per atomic, is the faster one.
     p.wave_ni = 0;
+    p.row_gather = 0;
+    p.units = 0;
     if (mode == yh::kModeDetect && max_candidates <= yh::kPostCap) {
-        const long ni = env_knob("YH_STREAM_NI", 8);             // tuning knob: 4, 8, anything else = workgroup tiles
-        if ((ni == 4 || ni == 8) && (256 * ni - 3) / p.K >= 1) p.wave_ni = (int32_t)ni;
-        else if (ni == 4 && (256 * 8 - 3) / p.K >= 1) p.wave_ni = 8;
+        // tuning knob: 1 = objectness-first variant (default), 2 = streaming variants
+        if (env_knob("YH_DETECT_KERNEL", 1) == 1) {
+            p.row_gather = 1;
+        } else {
+            const long ni = env_knob("YH_STREAM_NI", 8);         // tuning knob: 4, 8, anything else = workgroup tiles
+            if ((ni == 4 || ni == 8) && (256 * ni - 3) / p.K >= 1) p.wave_ni = (int32_t)ni;
+            else if (ni == 4 && (256 * 8 - 3) / p.K >= 1) p.wave_ni = 8;
+        }
+    }
+    if (p.row_gather) {
+        // a work unit = `steps` steps of 64 rows (one per lane) of one image and scale; an image's
+        // units are indexed by the candidates -> detections stage, so their number is bounded
+        uint64_t steps = (uint64_t)env_knob("YH_ROW_STEPS", 2);
+        for (;; ++steps) {
+            uint64_t upi = 0;
+            for (int s = 0; s < p.S; ++s) upi += ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
+            if (upi <= (uint64_t)yh::kMaxUnitsPerImage) break;
+        }
+        p.tile_rows = 64;
+        uint32_t units = 0, upi = 0;
+        for (int s = 0; s < p.S; ++s) {
+            const uint64_t chunks = ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
+            p.sc[s].tiles_per_chunk = (uint32_t)steps;
+            p.sc[s].chunks_per_img = (uint32_t)chunks;
+            p.sc[s].blk_begin = units;
+            p.sc[s].unit_base = upi;
+            units += (uint32_t)chunks * (uint32_t)B;
+            upi += (uint32_t)chunks;
+        }
+        p.upi = (int32_t)upi;
+        p.units = units;
+        const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
+        return (units + waves - 1) / waves;
     }
     if (p.wave_ni) {
         const long nb = env_knob("YH_STREAM_NBUF", 3);
@@ -428,7 +460,7 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
     d.q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
                           nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
                           out_class, out_index, out_class_candidates, status);
-    if (p.wave_ni) {                          // candidates arrive with slot-indexed boxes
+    if (p.wave_ni || p.row_gather) {          // candidates arrive with slot-indexed boxes
         d.q.upi = p.upi;
         d.q.ukeys = w.ukeys;
         d.q.uboxes = w.uboxes;
@@ -536,7 +568,8 @@ int yh_detect_pipelined(const yh_head_config *cfg, const float *const *heads, in
     }
     if (batch == 0 || (!heads && !prev_workspace)) return YH_OK;
     hipError_t e;
-    const bool fuse = heads && prev_workspace && cur.p.wave_ni && yh::select_fits_stream(prev.q);
+    const bool fuse = heads && prev_workspace &&
+                      ((cur.p.wave_ni && yh::select_fits_stream(prev.q)) || (cur.p.row_gather && yh::select_fits_rows(prev.q)));
     if (prev_workspace && !fuse && (e = yh::launch_nms_pipeline(prev.q, st)) != hipSuccess) return hip_fail(e, "nms launch");
     if (heads) {
         if (ev_b && (e = hipEventRecord(ev_b, st)) != hipSuccess) return hip_fail(e, "event record");

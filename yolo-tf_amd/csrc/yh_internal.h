@@ -74,6 +74,8 @@ struct StreamParams {
     int32_t tile_rows;      // rows per LDS tile: floor((tile floats - 3) / K)
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
+    int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
+    uint32_t units;         // objectness-first variant: work units of the launch
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     float thr;              // score threshold
     float prefilter;        // logits below this cannot reach thr
@@ -142,6 +144,9 @@ constexpr size_t kFuseLdsMax = 32 * 1024;   // largest LDS block of the stage wh
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
 bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
+bool select_fits_rows(const NmsParams &p);     // ... in a launch of the objectness-first variant
+constexpr int kRowsThreads = 512;           // objectness-first variant: eight wavefronts per workgroup
+constexpr size_t kRowsLdsMax = 40 * 1024;   // four such workgroups per compute unit
 
 // ---- loss ------------------------------------------------------------------
 struct LossScale {

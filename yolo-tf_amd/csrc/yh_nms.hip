@@ -384,6 +384,11 @@ bool select_fits_stream(const NmsParams &p)
     return single_launch_shape(p) && post_layout(p.cand_cap, p.C, p.max_boxes, 64).bytes <= kFuseLdsMax;
 }
 
+bool select_fits_rows(const NmsParams &p)
+{
+    return single_launch_shape(p) && post_layout(p.cand_cap, p.C, p.max_boxes, kRowsThreads).bytes <= kRowsLdsMax;
+}
+
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;

@@ -476,6 +476,124 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
     if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
 }
 
+// ------------------------------------------------------------ objectness-first variant
+// conf = sigmoid(x) * sigmoid(obj) >= thr needs sigmoid(obj) >= thr, so a row's class logits
+// matter only if its objectness passes the (conservatively lowered) logit(thr): with the
+// few-percent survival rate of a detector's head, most of the tensor need not be read at all.
+// A lane reads the objectness logit of one row (one float per K: the memory system fetches a
+// sector per row instead of the row, a fifth of the bytes at K = 85); the rows that pass are
+// then read whole, one at a time by the 64 lanes together (class logits spread over the
+// lanes, the four box channels in lanes 0-3), all loads of a row in flight at once, and the
+// next step's objectness logits are requested before the survivors are worked on.
+// Work units, private slots, the list for a unit's 17th and later candidates, and the
+// previous batch's candidates -> detections stage riding in the first q.B workgroups are
+// those of k_stream_wave.  A workgroup is eight wavefronts, each with units of its own.
+__global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams p, const NmsParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    if (blockIdx.x < (uint32_t)q.B) {
+        post_image_dyn<kRowsThreads>(q, (int)blockIdx.x, s_dyn);
+        return;
+    }
+    constexpr int kWaves = kRowsThreads / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *s_box = reinterpret_cast<float4 *>(s_dyn) + wave * kWaveStage;
+    unsigned long long *s_keys =
+        reinterpret_cast<unsigned long long *>(s_dyn + (size_t)kWaves * kWaveStage * 16) + wave * kWaveStage;
+    const uint32_t unit = (blockIdx.x - (uint32_t)q.B) * kWaves + (uint32_t)wave;
+    if (unit >= p.units) return;
+
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && unit >= p.sc[i].blk_begin) s = i;
+    const StreamScale &sc = p.sc[s];
+    const uint32_t r = unit - sc.blk_begin;
+    const int b = (int)(r / sc.chunks_per_img);
+    const uint32_t chunk = r - (uint32_t)b * sc.chunks_per_img;
+    const long long u = (long long)b * p.upi + sc.unit_base + chunk;   // this unit's index in the batch
+
+    const int K = p.K, C = p.C;
+    const float *img = sc.src + (long long)b * sc.span;
+    const uint32_t row_begin = chunk * sc.tiles_per_chunk * 64u;
+    uint32_t row_end = row_begin + sc.tiles_per_chunk * 64u;
+    if (row_end > sc.rows_img) row_end = sc.rows_img;
+    const float pf = p.prefilter;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    WaveOut o;
+    o.ukeys = p.ukeys + u * kUnitSlots;
+    o.uboxes = reinterpret_cast<float4 *>(p.uboxes) + u * kUnitSlots;
+    o.cand = p.cand + (long long)b * p.cand_cap;
+    o.cand_box = reinterpret_cast<float4 *>(p.cand_box) + (long long)b * p.cand_cap;
+    o.img_count = p.img_count + b;
+    o.cand_cap = p.cand_cap;
+    int count = 0;                                            // staged candidates, wave-uniform
+    int emitted = 0;                                          // candidates of this unit already written out
+
+    auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : -INFINITY; };
+    float obj_next = objectness(row_begin + (uint32_t)lane);
+    for (uint32_t row_t = row_begin; row_t < row_end; row_t += 64u) {
+        const float obj_l = obj_next;
+        obj_next = objectness(row_t + 64u + (uint32_t)lane);
+        unsigned long long mask = __ballot(obj_l >= pf);
+        while (mask) {                                        // wave-uniform: one surviving row per turn
+            const int bit = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t row = row_t + (uint32_t)bit;
+            const float *rp = img + (size_t)row * K;
+            const float x0 = lane < C ? rp[lane] : 0.0f;
+            const float x1 = 64 + lane < C ? rp[64 + lane] : 0.0f;
+            const float tb = lane < 4 ? rp[C + lane] : 0.0f;
+            const float so = sigmoidf(__shfl(obj_l, bit, 64));
+            const int n = (int)(sc.row_base + row);
+            bool have_box = false;
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c0 = 0; c0 < C; c0 += 64) {
+                const int c = c0 + lane;
+                const float x = c0 == 0 ? x0 : (c0 == 64 ? x1 : (c < C ? rp[c] : 0.0f));
+                bool hit = false;
+                float cf = 0.0f;
+                if (c < C && x >= pf) {
+                    cf = sigmoidf(x) * so;
+                    hit = cf >= p.thr;
+                }
+                const unsigned long long hm = __ballot(hit);
+                if (hm == 0) continue;
+                if (!have_box) {                              // the row's box, once, in every lane
+                    box = decode_box(p.P, sc, __shfl(tb, 0, 64), __shfl(tb, 1, 64), __shfl(tb, 2, 64),
+                                     __shfl(tb, 3, 64), row);
+                    have_box = true;
+                }
+                if (hit) {
+                    const int pos = count + __builtin_popcountll(hm & lanes_below);
+                    s_keys[pos] = make_key(c, cf, n);
+                    s_box[pos] = box;
+                }
+                count += __builtin_popcountll(hm);
+                if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
+            }
+        }
+    }
+    if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
+    if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
+}
+
+static hipError_t launch_rows(const StreamParams &p, uint32_t blocks, hipStream_t stm, const NmsParams &q)
+{
+    size_t lds = (size_t)(kRowsThreads / 64) * kWaveStage * (16 + 8);
+    if (q.B > 0) {
+        const size_t need = post_layout(q.cand_cap, q.C, q.max_boxes, kRowsThreads).bytes;
+        lds = need > lds ? need : lds;
+    }
+    if (lds > 48 * 1024) {                    // beyond the default limit of dynamic LDS
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_detect_rows),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_detect_rows, dim3(blocks + (uint32_t)q.B), dim3(kRowsThreads), lds, stm, p, q);
+    return hipGetLastError();
+}
+
 // Full decode (yh_decode): boxes [B][N][4] and, optionally, conf [B][N][C].
 // grid = (ceil(span / 256), B) per scale: one element of the head per lane,
 // coalesced loads and stores; the row's objectness comes from the cache.
@@ -546,7 +664,7 @@ hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t stm)
 
 hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t stm, const NmsParams *fused)
 {
-    if (fused && !(mode == kModeDetect && p.wave_ni)) return hipErrorInvalidValue;
+    if (fused && !(mode == kModeDetect && (p.wave_ni || p.row_gather))) return hipErrorInvalidValue;
     if (mode == kModeFull) {
         for (int s = 0; s < p.S; ++s) {
             const dim3 grid((p.sc[s].span + kThreads - 1) / kThreads, (uint32_t)p.B);
@@ -555,6 +673,13 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
+    }
+    if (mode == kModeDetect && p.row_gather) {
+        NmsParams none;
+        std::memset(&none, 0, sizeof(none));
+        const NmsParams &q = fused ? *fused : none;
+        if (blocks == 0 && q.B == 0) return hipSuccess;
+        return launch_rows(p, blocks, stm, q);
     }
     if (mode == kModeDetect && p.wave_ni) {
         NmsParams none;

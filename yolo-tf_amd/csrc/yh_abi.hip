@@ -180,29 +180,30 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         }
     }
     if (p.row_gather) {
-        // a work unit = `steps` steps of 64 rows (one per lane) of one image and scale; an image's
-        // units are indexed by the candidates -> detections stage, so their number is bounded
+        // a work unit = `steps` steps of 64 rows (one per lane) of one image and scale; a workgroup
+        // takes eight consecutive units of one image (the last workgroup of an image may hold spare
+        // ones); an image's units are indexed by the candidates -> detections stage, so their
+        // number is bounded
+        const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
         uint64_t steps = (uint64_t)env_knob("YH_ROW_STEPS", 2);
         for (;; ++steps) {
             uint64_t upi = 0;
             for (int s = 0; s < p.S; ++s) upi += ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
-            if (upi <= (uint64_t)yh::kMaxUnitsPerImage) break;
+            if ((upi + waves - 1) / waves * waves <= (uint64_t)yh::kMaxUnitsPerImage) break;
         }
         p.tile_rows = 64;
-        uint32_t units = 0, upi = 0;
+        uint32_t upi = 0;
         for (int s = 0; s < p.S; ++s) {
             const uint64_t chunks = ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
             p.sc[s].tiles_per_chunk = (uint32_t)steps;
             p.sc[s].chunks_per_img = (uint32_t)chunks;
-            p.sc[s].blk_begin = units;
+            p.sc[s].blk_begin = 0;
             p.sc[s].unit_base = upi;
-            units += (uint32_t)chunks * (uint32_t)B;
             upi += (uint32_t)chunks;
         }
-        p.upi = (int32_t)upi;
-        p.units = units;
-        const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
-        return (units + waves - 1) / waves;
+        p.units = (upi + waves - 1) / waves;                     // workgroups per image
+        p.upi = (int32_t)(p.units * waves);
+        return p.units * (uint32_t)B;
     }
     if (p.wave_ni) {
         const long nb = env_knob("YH_STREAM_NBUF", 3);

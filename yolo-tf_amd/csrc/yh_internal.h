@@ -75,7 +75,7 @@ struct StreamParams {
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
     int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
-    uint32_t units;         // objectness-first variant: work units of the launch
+    uint32_t units;         // objectness-first variant: workgroups per image (eight units each)
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     float thr;              // score threshold
     float prefilter;        // logits below this cannot reach thr

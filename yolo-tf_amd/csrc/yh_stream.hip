@@ -480,14 +480,27 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
 // conf = sigmoid(x) * sigmoid(obj) >= thr needs sigmoid(obj) >= thr, so a row's class logits
 // matter only if its objectness passes the (conservatively lowered) logit(thr): with the
 // few-percent survival rate of a detector's head, most of the tensor need not be read at all.
-// A lane reads the objectness logit of one row (one float per K: the memory system fetches a
-// sector per row instead of the row, a fifth of the bytes at K = 85); the rows that pass are
-// then read whole, one at a time by the 64 lanes together (class logits spread over the
-// lanes, the four box channels in lanes 0-3), all loads of a row in flight at once, and the
-// next step's objectness logits are requested before the survivors are worked on.
-// Work units, private slots, the list for a unit's 17th and later candidates, and the
-// previous batch's candidates -> detections stage riding in the first q.B workgroups are
-// those of k_stream_wave.  A workgroup is eight wavefronts, each with units of its own.
+//
+// A workgroup is eight wavefronts on consecutive work units of ONE image (a unit: `steps`
+// steps of 64 rows of one scale).  Per round of two steps:
+//   1. a lane reads the objectness logit of one row (one float per K: the memory system
+//      fetches a cache line per row instead of the row, three eighths of the bytes at K = 85);
+//      two steps' logits are requested together (a "round");
+//   2. the rows that pass go into a queue in LDS shared by the eight wavefronts;
+//   3. the wavefronts take the queue's rows four at a time, whichever unit they came from,
+//      so that a unit with many surviving rows does not become the launch's tail: all loads of
+//      the four rows in flight at once (class logits spread over the lanes, the box channels
+//      in lanes 0-3), exact test, box decode, (key, box) staged per wavefront.
+// A wavefront writes what it staged into the private slots of its own unit (any unit of the
+// image will do: keys carry the box row), the 17th and later candidates into the image's
+// list, exactly as k_stream_wave does, and the previous batch's candidates -> detections
+// stage rides in the first q.B workgroups in the same way.
+constexpr int kRowsWaves = kRowsThreads / 64;
+constexpr int kRowsRound = 2;                 // steps whose objectness logits are requested together
+constexpr int kRowsQueue = kRowsRound * kRowsThreads;   // rows one round of a workgroup looks at
+constexpr int kRowsGather = 4;
+constexpr size_t kRowsLds = (size_t)kRowsWaves * kWaveStage * (16 + 8) + (size_t)kRowsQueue * 8 + 16;
+
 __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams p, const NmsParams q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -495,31 +508,35 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
         post_image_dyn<kRowsThreads>(q, (int)blockIdx.x, s_dyn);
         return;
     }
-    constexpr int kWaves = kRowsThreads / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 *s_box = reinterpret_cast<float4 *>(s_dyn) + wave * kWaveStage;
-    unsigned long long *s_keys =
-        reinterpret_cast<unsigned long long *>(s_dyn + (size_t)kWaves * kWaveStage * 16) + wave * kWaveStage;
-    const uint32_t unit = (blockIdx.x - (uint32_t)q.B) * kWaves + (uint32_t)wave;
-    if (unit >= p.units) return;
+    unsigned char *at = s_dyn + (size_t)kRowsWaves * kWaveStage * 16;
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(at) + wave * kWaveStage;
+    at += (size_t)kRowsWaves * kWaveStage * 8;
+    uint32_t *s_qrow = reinterpret_cast<uint32_t *>(at);            // [kRowsQueue]: (scale << 28) | row inside the scale
+    float *s_qobj = reinterpret_cast<float *>(at + (size_t)kRowsQueue * 4);   // [kRowsQueue]
+    int *s_qn = reinterpret_cast<int *>(at + (size_t)kRowsQueue * 8);         // [3] queue lengths, used in turn
+    if (threadIdx.x < 3) s_qn[threadIdx.x] = 0;
 
+    const uint32_t g = blockIdx.x - (uint32_t)q.B;
+    const int b = (int)(g / p.units);                         // p.units: workgroups per image
+    const uint32_t ui = (g - (uint32_t)b * p.units) * kRowsWaves + (uint32_t)wave;   // unit inside the image (< p.upi)
     int s = 0;
 #pragma unroll
     for (int i = 1; i < YH_MAX_SCALES; ++i)
-        if (i < p.S && unit >= p.sc[i].blk_begin) s = i;
+        if (i < p.S && ui >= p.sc[i].unit_base) s = i;
     const StreamScale &sc = p.sc[s];
-    const uint32_t r = unit - sc.blk_begin;
-    const int b = (int)(r / sc.chunks_per_img);
-    const uint32_t chunk = r - (uint32_t)b * sc.chunks_per_img;
-    const long long u = (long long)b * p.upi + sc.unit_base + chunk;   // this unit's index in the batch
-
+    const uint32_t chunk = ui - sc.unit_base;
+    const bool has_rows = chunk < sc.chunks_per_img;          // the image's last workgroup may hold spare units
     const int K = p.K, C = p.C;
+    const uint32_t steps = p.sc[0].tiles_per_chunk;           // the same for every scale
     const float *img = sc.src + (long long)b * sc.span;
-    const uint32_t row_begin = chunk * sc.tiles_per_chunk * 64u;
-    uint32_t row_end = row_begin + sc.tiles_per_chunk * 64u;
+    const uint32_t row_begin = chunk * steps * 64u;
+    uint32_t row_end = has_rows ? row_begin + steps * 64u : row_begin;
     if (row_end > sc.rows_img) row_end = sc.rows_img;
     const float pf = p.prefilter;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const long long u = (long long)b * p.upi + ui;
     WaveOut o;
     o.ukeys = p.ukeys + u * kUnitSlots;
     o.uboxes = reinterpret_cast<float4 *>(p.uboxes) + u * kUnitSlots;
@@ -531,48 +548,86 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     int emitted = 0;                                          // candidates of this unit already written out
 
     auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : -INFINITY; };
-    float obj_next = objectness(row_begin + (uint32_t)lane);
-    for (uint32_t row_t = row_begin; row_t < row_end; row_t += 64u) {
-        const float obj_l = obj_next;
-        obj_next = objectness(row_t + 64u + (uint32_t)lane);
-        unsigned long long mask = __ballot(obj_l >= pf);
-        while (mask) {                                        // wave-uniform: one surviving row per turn
-            const int bit = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t row = row_t + (uint32_t)bit;
-            const float *rp = img + (size_t)row * K;
-            const float x0 = lane < C ? rp[lane] : 0.0f;
-            const float x1 = 64 + lane < C ? rp[64 + lane] : 0.0f;
-            const float tb = lane < 4 ? rp[C + lane] : 0.0f;
-            const float so = sigmoidf(__shfl(obj_l, bit, 64));
-            const int n = (int)(sc.row_base + row);
-            bool have_box = false;
-            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int c0 = 0; c0 < C; c0 += 64) {
-                const int c = c0 + lane;
-                const float x = c0 == 0 ? x0 : (c0 == 64 ? x1 : (c < C ? rp[c] : 0.0f));
-                bool hit = false;
-                float cf = 0.0f;
-                if (c < C && x >= pf) {
-                    cf = sigmoidf(x) * so;
-                    hit = cf >= p.thr;
+    __syncthreads();
+    for (uint32_t t = 0, round = 0; t < steps; t += kRowsRound, ++round) {
+        int *qn = s_qn + round % 3u;
+        // 1, 2: this round's rows; survivors into the queue
+        float obj_l[kRowsRound];
+#pragma unroll
+        for (int j = 0; j < kRowsRound; ++j)
+            obj_l[j] = t + j < steps ? objectness(row_begin + (t + j) * 64u + (uint32_t)lane) : -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kRowsRound; ++j) {
+            const unsigned long long mask = __ballot(obj_l[j] >= pf);
+            if (mask) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(qn, __builtin_popcountll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if ((mask >> lane) & 1ull) {
+                    const int e = base + __builtin_popcountll(mask & lanes_below);
+                    s_qrow[e] = ((uint32_t)s << 28) | (row_begin + (t + j) * 64u + (uint32_t)lane);
+                    s_qobj[e] = obj_l[j];
                 }
-                const unsigned long long hm = __ballot(hit);
-                if (hm == 0) continue;
-                if (!have_box) {                              // the row's box, once, in every lane
-                    box = decode_box(p.P, sc, __shfl(tb, 0, 64), __shfl(tb, 1, 64), __shfl(tb, 2, 64),
-                                     __shfl(tb, 3, 64), row);
-                    have_box = true;
-                }
-                if (hit) {
-                    const int pos = count + __builtin_popcountll(hm & lanes_below);
-                    s_keys[pos] = make_key(c, cf, n);
-                    s_box[pos] = box;
-                }
-                count += __builtin_popcountll(hm);
-                if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) s_qn[(round + 2u) % 3u] = 0;   // last read a round ago, next used two barriers from here
+        const int total = *qn;
+        // 3: the queue's rows, kRowsGather per wavefront and turn
+        for (int e0 = wave * kRowsGather; e0 < total; e0 += kRowsWaves * kRowsGather) {
+            float x0[kRowsGather], x1[kRowsGather], tb[kRowsGather], ob[kRowsGather];
+            uint32_t code[kRowsGather];
+#pragma unroll
+            for (int k = 0; k < kRowsGather; ++k) {
+                if (e0 + k < total) {
+                    code[k] = s_qrow[e0 + k];
+                    ob[k] = s_qobj[e0 + k];
+                    const int es = __builtin_amdgcn_readfirstlane((int)(code[k] >> 28));
+                    const StreamScale &esc = p.sc[es];
+                    const float *rp = esc.src + (long long)b * esc.span + (size_t)(code[k] & 0x0fffffffu) * K;
+                    x0[k] = lane < C ? rp[lane] : 0.0f;
+                    x1[k] = 64 + lane < C ? rp[64 + lane] : 0.0f;
+                    tb[k] = lane < 4 ? rp[C + lane] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kRowsGather; ++k) {
+                if (e0 + k >= total) break;
+                const int es = __builtin_amdgcn_readfirstlane((int)(code[k] >> 28));
+                const StreamScale &esc = p.sc[es];
+                const uint32_t row = code[k] & 0x0fffffffu;
+                const float *rp = esc.src + (long long)b * esc.span + (size_t)row * K;
+                const float so = sigmoidf(ob[k]);
+                const int n = (int)(esc.row_base + row);
+                bool have_box = false;
+                float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c0 = 0; c0 < C; c0 += 64) {
+                    const int c = c0 + lane;
+                    const float x = c0 == 0 ? x0[k] : (c0 == 64 ? x1[k] : (c < C ? rp[c] : 0.0f));
+                    bool hit = false;
+                    float cf = 0.0f;
+                    if (c < C && x >= pf) {
+                        cf = sigmoidf(x) * so;
+                        hit = cf >= p.thr;
+                    }
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm == 0) continue;
+                    if (!have_box) {                          // the row's box, once, in every lane
+                        box = decode_box(p.P, esc, __shfl(tb[k], 0, 64), __shfl(tb[k], 1, 64), __shfl(tb[k], 2, 64),
+                                         __shfl(tb[k], 3, 64), row);
+                        have_box = true;
+                    }
+                    if (hit) {
+                        const int pos = count + __builtin_popcountll(hm & lanes_below);
+                        s_keys[pos] = make_key(c, cf, n);
+                        s_box[pos] = box;
+                    }
+                    count += __builtin_popcountll(hm);
+                    if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
+                }
+            }
+        }
+        if (t + kRowsRound < steps) __syncthreads();          // the queue is rewritten by the next round
     }
     if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
     if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
@@ -580,7 +635,7 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
 
 static hipError_t launch_rows(const StreamParams &p, uint32_t blocks, hipStream_t stm, const NmsParams &q)
 {
-    size_t lds = (size_t)(kRowsThreads / 64) * kWaveStage * (16 + 8);
+    size_t lds = kRowsLds;
     if (q.B > 0) {
         const size_t need = post_layout(q.cand_cap, q.C, q.max_boxes, kRowsThreads).bytes;
         lds = need > lds ? need : lds;

@@ -23,6 +23,41 @@ __global__ __launch_bounds__(256) void k_strided(const float *src, long long row
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+template <int U>
+__global__ __launch_bounds__(256) void k_strided_nt(const float *src, long long rows, int K, int ch, float *sink)
+{
+    const long long base = ((long long)blockIdx.x * 256 * U) + threadIdx.x;
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long r = base + (long long)u * 256;
+        v[u] = r < rows ? __builtin_nontemporal_load(src + r * K + ch) : 0.0f;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = fmaxf(acc, v[u]);
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+// sc1 sc0: system-scope, bypassing the caches' allocation
+template <int U>
+__global__ __launch_bounds__(256) void k_strided_sc(const float *src, long long rows, int K, int ch, float *sink)
+{
+    const long long base = ((long long)blockIdx.x * 256 * U) + threadIdx.x;
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long r = base + (long long)u * 256;
+        const float *ptr = src + (r < rows ? r : rows - 1) * K + ch;
+        asm volatile("global_load_dword %0, %1, off sc0 sc1 nt" : "=v"(v[u]) : "v"(ptr) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = fmaxf(acc, v[u]);
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 int main()
 {
     const int K = 85;
@@ -49,5 +84,12 @@ int main()
         time_it(name, [&](float *b) { hipLaunchKernelGGL(k_strided<U>, dim3(blocks), dim3(256), 0, 0, b, rows, K, K - 1, sink); }); \
     } while (0)
     RUN(1); RUN(2); RUN(4); RUN(8);
+#define RUN2(KERN, LABEL, U) do { \
+        snprintf(name, sizeof name, LABEL ", %d rows/lane", U); \
+        const int blocks = (int)((rows + 256LL * U - 1) / (256LL * U)); \
+        time_it(name, [&](float *b) { hipLaunchKernelGGL(KERN<U>, dim3(blocks), dim3(256), 0, 0, b, rows, K, K - 1, sink); }); \
+    } while (0)
+    RUN2(k_strided_nt, "nontemporal", 1); RUN2(k_strided_nt, "nontemporal", 2);
+    RUN2(k_strided_sc, "sc0 sc1 nt", 1); RUN2(k_strided_sc, "sc0 sc1 nt", 2);
     return 0;
 }

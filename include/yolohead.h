@@ -168,8 +168,8 @@ int yh_detect_select(const yh_head_config *cfg, int32_t batch,
  * The outputs and status belong to batch i-1.  Both workspaces have
  * workspace_bytes bytes; the caller alternates between two.  When the select
  * stage's bounds do not allow it to ride in the streaming launch (see
- * yh_detect_workspace_bytes: the single-launch form, and about 32 KiB of LDS,
- * e.g. max_candidates <= 512 at 80 classes x 10 boxes) the two stages run one
+ * yh_detect_workspace_bytes: the single-launch form, and about 40 KiB of LDS,
+ * e.g. max_candidates <= 704 at 80 classes x 10 boxes) the two stages run one
  * after the other, with the same results.  event_begin / event_end as in
  * yh_detect_timed.  No counterpart in the reference, whose session.run is
  * synchronous; results per batch are those of yh_detect. */

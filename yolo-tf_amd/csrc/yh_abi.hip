@@ -146,7 +146,7 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 }
 
 // Fills the per-scale block decomposition of the streaming pass.  A workgroup
-// walks tiles of whole rows (<= 32 KiB each) and ends with a latency-bound tail
+// walks tiles of whole rows (<= 20 KiB each) and ends with a latency-bound tail
 // (the atomic that reserves its candidate range), so the launch is
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
@@ -163,9 +163,10 @@ long env_knob(const char *name, long fallback)
 
 uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t max_candidates = 0)
 {
-    // The detection pass runs wave-private tiles of 4 or 8 KiB when a row fits one.  A capacity
-    // beyond the single-launch select stage announces a dense candidate set (low thresholds): there
-    // the workgroup-tile variant, which appends 512 candidates per atomic, is the faster one.
+    // The detection pass is objectness-first (or, by the knob, wave-private tiles of 4 or 8 KiB when a
+    // row fits one).  A capacity beyond the single-launch select stage announces a dense candidate set
+    // (low thresholds): there the workgroup-tile variant, which reads the whole head and appends a few
+    // hundred candidates per atomic, is the faster one.
     p.wave_ni = 0;
     p.row_gather = 0;
     p.units = 0;

@@ -3,7 +3,7 @@
 //
 // The NHWC head of one scale is a row-major matrix [B * rows_img][K], K = C + 5,
 // one row per box.  A workgroup walks tiles of whole rows of one image.  A tile
-// (up to 32 KiB) goes from HBM straight into LDS with LDS-DMA loads
+// (up to 20 KiB) goes from HBM straight into LDS with LDS-DMA loads
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination,
 // no VALU work), issued back to back so that the whole tile is in flight at
 // once; the 16-byte phase of the tile start is absorbed by an aligned window
@@ -15,14 +15,20 @@
 //      conf = sigmoid(x) * sigmoid(obj) <= min(sigmoid(x), sigmoid(obj)),
 //      a row whose objectness is below a conservatively lowered logit(thr)
 //      cannot yield a candidate and is dropped with a single compare;
-//   B. the surviving rows' class logits are spread over all lanes; those that
-//      pass the same prefilter get the exact sigmoid product and threshold, and
-//      real candidates decode their box from the tile and stage a key.
+//   B. the surviving rows' class logits are spread over all lanes: one pass
+//      collects the items that pass the same prefilter, a second, dense pass
+//      gives them the exact sigmoid product and threshold, and real candidates
+//      decode their box from the tile and stage a key.
 // The [N][C] confidence matrix is never materialised and nothing is read
-// twice from memory.  One global atomic per workgroup reserves the range in
-// the image's candidate list; the launch is oversubscribed (a few thousand
-// short workgroups) so that this latency-bound tail overlaps other workgroups'
-// streaming.
+// twice from memory.  One global atomic per flush of the staged keys reserves
+// the range in the image's candidate list; the launch is oversubscribed (a few
+// thousand short workgroups) so that this latency-bound tail overlaps other
+// workgroups' streaming.
+//
+// Three kernels share this file: k_stream (workgroup tiles, described above:
+// dense candidate sets, yh_nms), k_stream_wave (wave-private ring of tiles,
+// reads the whole head without barriers) and k_detect_rows (objectness-first:
+// does not read the whole head; the default of yh_detect).
 #include <cstring>
 #include "yh_post.h"
 

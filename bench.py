@@ -200,17 +200,34 @@ def main():
                 for h in hs:
                     h.requires_grad_(True)
 
+        def step_autograd(i):
+            hs = sets[i % ROTATE]
+            for h in hs:
+                h.grad = None
+            total, _ = hd.loss_with_grad(hs, gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
+            (0.5 * total.reshape(()) / y.parallel.global_batch(B)).backward()
+            return y.parallel.global_mean_loss(total.detach(), B)
+
         def step(i, events=None):
             if w.get('backward'):
-                hs = sets[i % ROTATE]
-                for h in hs:
-                    h.grad = None
-                total, _ = hd.loss_with_grad(hs, gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
-                (0.5 * total.reshape(()) / y.parallel.global_batch(B)).backward()
-                return y.parallel.global_mean_loss(total.detach(), B)
+                # forward + backward as two library calls: d(.5 * mean loss) / d(head) for every head
+                out, _grads = hd.loss_and_grad(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True,
+                                               grad_scale=0.5 / y.parallel.global_batch(B))
+                return y.parallel.global_mean_loss(out['sum'], B)
             out = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
             return y.parallel.global_mean_loss(out['sum'], B)   # the data-parallel scalar all-reduce
         extra = {}
+        if w.get('backward'):
+            for i in range(5):
+                step_autograd(i)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(30):
+                step_autograd(i)
+            torch.cuda.synchronize(dev)
+            extra = {'through_autograd_ms_per_step': round((time.perf_counter() - t0) / 30 * 1e3, 5),
+                     'note': 'timed: loss_and_grad (two library calls); through_autograd = the same step via '
+                             'torch.autograd (loss_with_grad + backward()), host-bound by the engine'}
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -424,6 +424,23 @@ def test_loss_backward_matches_oracle(gpu, version, B, G):
             assert np.array_equal(got == 0, w == 0) or np.count_nonzero((got == 0) != (w == 0)) <= 2
 
 
+def test_loss_and_grad_equals_the_autograd_path(gpu):
+    """Forward + backward as two library calls give the bits torch.autograd gets from
+    loss_with_grad for the same upstream factor."""
+    case = cases.v3(size=96)
+    B = 3
+    heads = to_dev(case.heads(91, B, obj_mean=-1.0), gpu)
+    gt = torch.from_numpy(y.synth.make_ground_truth(92, B, 5, 9, 96, case.C)).to(gpu)
+    hd = case.head_obj()
+    out, grads = hd.loss_and_grad(heads, gt, 1., 1., 5., 1., 0.5, True, grad_scale=0.5 / B)
+    leaves = [h.clone().requires_grad_(True) for h in heads]
+    total, per = hd.loss_with_grad(leaves, gt, 1., 1., 5., 1., 0.5, True)
+    (0.5 * total.reshape(()) / B).backward()
+    assert torch.equal(out['per_image'], per.detach()) and torch.equal(out['sum'], total.detach())
+    for g, l in zip(grads, leaves):
+        assert torch.equal(g, l.grad)
+
+
 def test_loss_backward_is_the_derivative_of_the_forward(gpu):
     """Directional finite difference of the GPU loss itself (fp32 forward evaluated at
     +-eps along a random direction) against <grad, direction>: 1e-3, the resolution of

@@ -332,6 +332,26 @@ class DetectionHead:
                                             _abi.pointer_array([g.data_ptr() for g in grads]), self._stream(dev)))
         return grads
 
+    def loss_and_grad(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                      ignore_threshold, normalize_by_num_gt, grad_scale=1.0):
+        """Forward and backward in two library calls, without an autograd graph:
+        (loss() result, [d(grad_scale * sum of the per-image losses) / d(head)]).
+        For training loops that hand the gradients on themselves
+        (torch.autograd.backward(heads, grads)) and do not want the autograd
+        engine's thread hand-over between the two kernels."""
+        out = self.loss(heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                        ignore_threshold, normalize_by_num_gt, want_mask=True)
+        B, dev = heads[0].shape[0], heads[0].device
+        key = (B, float(grad_scale), dev)
+        gw = self._grad_weights.get(key) if hasattr(self, '_grad_weights') else None
+        if gw is None:
+            if not hasattr(self, '_grad_weights'):
+                self._grad_weights = {}
+            gw = self._grad_weights[key] = torch.full((B,), float(grad_scale), dtype=torch.float32, device=dev)
+        grads = self.loss_backward(heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                                   normalize_by_num_gt, out['noobj_mask'], gw)
+        return out, grads
+
     def loss_with_grad(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                        ignore_threshold, normalize_by_num_gt):
         """(sum of the per-image losses [1], per-image losses [B]) as tensors that

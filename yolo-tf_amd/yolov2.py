@@ -128,17 +128,18 @@ class YOLOv2:
     def _train_step(self, head, ground_truth, lr):
         """One optimisation step when the head tensor carries an autograd graph
         (optimizer.minimize, YOLOv2.py:175-181); see YOLOv3._train_step."""
-        total_sum, _ = self.head.loss_with_grad([head], ground_truth, self.coord_sacle, self.noobj_scale,
-                                                self.obj_scale, self.class_scale, 0.6, False)
         local_b = head.shape[0]
+        out, grads = self.head.loss_and_grad([head.detach()], ground_truth, self.coord_sacle, self.noobj_scale,
+                                             self.obj_scale, self.class_scale, 0.6, False,
+                                             grad_scale=1.0 / parallel.global_batch(local_b))
         zero = getattr(self.head_provider, 'zero_grad', None)
         if zero is not None:
             zero()
-        (total_sum.reshape(()) / parallel.global_batch(local_b)).backward()
+        torch.autograd.backward([head], grads)               # d(total_loss) / d(head) into the network
         step = getattr(self.head_provider, 'step', None)
         if step is not None:
             step(lr)
-        return parallel.global_mean_loss(total_sum.detach(), local_b)
+        return parallel.global_mean_loss(out['sum'], local_b)
 
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)

@@ -154,17 +154,18 @@ class YOLOv3:
         total_loss through the fused loss into the provider's network, then the
         provider's `step(lr)`.  The weight-decay term belongs to the provider,
         which owns the weights.  Returns total_loss (global mean, detached)."""
-        total_sum, _ = self.head.loss_with_grad(heads, ground_truth, self.coord_sacle, self.noobj_scale,
-                                                self.obj_scale, self.class_scale, 0.5, True)
         local_b = heads[0].shape[0]
+        out, grads = self.head.loss_and_grad([h.detach() for h in heads], ground_truth, self.coord_sacle,
+                                             self.noobj_scale, self.obj_scale, self.class_scale, 0.5, True,
+                                             grad_scale=loss_factor / parallel.global_batch(local_b))
         zero = getattr(self.head_provider, 'zero_grad', None)
         if zero is not None:
             zero()
-        (loss_factor * total_sum.reshape(()) / parallel.global_batch(local_b)).backward()
+        torch.autograd.backward(heads, grads)                # d(loss_factor * total_loss) / d(head) into the network
         step = getattr(self.head_provider, 'step', None)
         if step is not None:
             step(lr)
-        return parallel.global_mean_loss(total_sum.detach(), local_b)
+        return parallel.global_mean_loss(out['sum'], local_b)
 
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)

@@ -213,9 +213,9 @@ def main():
                 # forward + backward as two library calls: d(.5 * mean loss) / d(head) for every head
                 out, _grads = hd.loss_and_grad(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True,
                                                grad_scale=0.5 / y.parallel.global_batch(B))
-                return y.parallel.global_mean_loss(out['sum'], B)
+                return y.parallel.global_mean_loss(out['sum'], B, out['mean'])
             out = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
-            return y.parallel.global_mean_loss(out['sum'], B)   # the data-parallel scalar all-reduce
+            return y.parallel.global_mean_loss(out['sum'], B, out['mean'])   # the data-parallel scalar all-reduce
         extra = {}
         if w.get('backward'):
             for i in range(5):

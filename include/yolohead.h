@@ -206,9 +206,11 @@ int yh_nms(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
  *                             0: do not (YOLOv2.py:172);
  *   loss_per_image [B]; loss_parts [B][4] = coord, class, obj, noobj sums, may
  *   be NULL; iou_max [B][N] = ignore-mask IoU maximum of every box (NaN in
- *   cells holding a GT centre), may be NULL; loss_sum [1] = sum over the
- *   batch's images (the value a data-parallel caller all-reduces before
- *   dividing by the global batch, YOLOv3.py:311). */
+ *   cells holding a GT centre), may be NULL; loss_sum [2], may be NULL:
+ *   [0] = sum over the batch's images (the value a data-parallel caller
+ *   all-reduces before dividing by the global batch), [1] = that sum divided
+ *   by `batch` in fp32 (reduce_mean over this call's images, YOLOv3.py:311:
+ *   the total_loss of a single-process caller). */
 int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pad, size_t *bytes);
 int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
             int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,

@@ -369,6 +369,7 @@ def test_loss_v3_matches_oracle(gpu, c_oracle, G, B):
     assert_close(out['parts'].cpu().numpy(), parts, what='loss parts')
     assert_close(out['per_image'].cpu().numpy(), per, what='per-image loss')
     assert_close(out['sum'].item() / B, mean, what='mean loss')
+    assert np.float32(out['mean'].item()) == np.float32(out['sum'].item()) / np.float32(B)     # the kernel's own fp32 mean
     # NumPy restatement, image 0
     n0 = O.loss_v3_image([h[0] for h in heads], gt[0], case.priors, case.C)
     assert_close(out['per_image'][0].item(), n0, what='loss vs numpy')

@@ -174,7 +174,7 @@ struct LossParams {
     float *loss_per_image;        // [B]
     float *loss_parts;            // [B][4] or null
     float *iou_max;               // [B][N] or null
-    float *loss_sum;              // [1]
+    float *loss_sum;              // [2]: sum, mean over the call's images
     uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
     const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
     LossScale sc[YH_MAX_SCALES];

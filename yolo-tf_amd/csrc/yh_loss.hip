@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossPa
     if (tid == 0 && p.loss_sum) {
         double acc = 0.0;
         for (int g = 0; g < kFinalizeGroups; ++g) acc += s_sum[g];
-        *p.loss_sum = (float)acc;
+        p.loss_sum[0] = (float)acc;
+        p.loss_sum[1] = (float)acc / (float)p.B;              // reduce_mean over this call's images, in fp32
     }
 }
 

@@ -277,7 +277,7 @@ class DetectionHead:
              ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False):
         """Per-image training loss (YOLOv3.py:117-310 / YOLOv2.py:105-173).
         ground_truth: [B, pad, 5] float32 CUDA tensor, -1 padded.
-        Returns dict(per_image [B], sum [1], parts [B,4] | None, iou_max [B,N] | None,
+        Returns dict(per_image [B], sum [1], mean [1] (sum / B), parts [B,4] | None, iou_max [B,N] | None,
         noobj_mask [B,N] uint8 | None: what loss_backward needs).  No autograd
         graph is recorded here: loss_with_grad does that."""
         lib = _abi.load()
@@ -295,7 +295,7 @@ class DetectionHead:
         _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
         ws = self._workspace(('loss', B, N, pad), nbytes.value, dev)
         per = torch.empty((B,), dtype=torch.float32, device=dev)
-        total = torch.empty((1,), dtype=torch.float32, device=dev)
+        total = torch.empty((2,), dtype=torch.float32, device=dev)      # sum, mean over this call's images
         parts = torch.empty((B, 4), dtype=torch.float32, device=dev) if want_parts else None
         iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
         mask = torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None
@@ -307,7 +307,7 @@ class DetectionHead:
                                            per.data_ptr(), parts.data_ptr() if want_parts else None,
                                            iou.data_ptr() if want_iou_max else None, total.data_ptr(),
                                            mask.data_ptr() if want_mask else None, self._stream(dev)))
-        return dict(per_image=per, sum=total, parts=parts, iou_max=iou, noobj_mask=mask)
+        return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask)
 
     def loss_backward(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                       normalize_by_num_gt, noobj_mask, grad_per_image):

@@ -42,14 +42,18 @@ def global_batch(local_batch):
     return int(local_batch)
 
 
-def global_mean_loss(local_sum, local_batch):
+def global_mean_loss(local_sum, local_batch, local_mean=None):
     """reduce_mean over the global batch.  local_sum: tensor [1] (or 0-dim)
-    holding this rank's sum of per-image losses.  Returns a 0-dim float32
-    tensor on local_sum's device, identical on every rank."""
+    holding this rank's sum of per-image losses; local_mean: the same sum
+    already divided by local_batch in fp32 (the loss kernel writes both), used
+    as it is when there is one rank.  Returns a 0-dim float32 tensor on
+    local_sum's device, identical on every rank."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         buf = torch.empty(2, dtype=torch.float64, device=local_sum.device)
         buf[0] = local_sum.reshape(())
         buf[1] = float(local_batch)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return (buf[0] / buf[1]).to(torch.float32)
+    if local_mean is not None:
+        return local_mean.reshape(())                           # one rank: the fp32 mean, taken in the loss kernel
     return local_sum.reshape(()) / float(local_batch)          # one rank: the fp32 mean the reference computes

@@ -148,6 +148,10 @@ def main():
     ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
                     help='detect workloads: 2 = software pipeline (a step streams batch i and selects batch '
                          'i-1 in one launch), 1 = every batch runs to completion before the next')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='detect workloads, --in-flight 2: pipelines on streams of their own, fed in turn (the '
+                         'latency-bound tail of one launch overlaps the bandwidth-bound start of the next); '
+                         '1 = one stream, launches back to back')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -183,14 +187,21 @@ def main():
         # --in-flight 1 runs every batch to completion before the next (yh_detect).
         lanes = 2 if args.in_flight > 1 else 1
         outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
-        pipe = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes']) if lanes > 1 else None
+        # several streams only where a step is one launch (small candidate capacity)
+        nstreams = max(1, args.streams) if (lanes > 1 and args.workload != 'stress') else 1
+        pipe = None
+        if lanes > 1:
+            pipe = (y.DetectLanes(hd, w['thr'], w['iou'], w['max_boxes'], lanes=nstreams, device=dev) if nstreams > 1
+                    else y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes']))
 
         def step(i, events=None):
+            if pipe is not None and nstreams > 1:
+                return pipe.submit(sets[i % ROTATE])          # the inputs are resident: nothing to wait for
             if pipe is not None:
                 return pipe.submit(sets[i % ROTATE], stream_events=events)
             return hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs,
                              stream_events=events)
-        extra = {'batches_in_flight': lanes}
+        extra = {'batches_in_flight': lanes * nstreams, 'streams': nstreams}
     else:
         gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
                for i in range(ROTATE)]
@@ -255,16 +266,21 @@ def main():
     span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     one_launch_per_step = (w['kind'] == 'detect' and pipe is not None and
                            hd.default_max_candidates(N) <= hd.SMALL_CAPACITY)   # the select stage rides along
+    # With several streams the pair sits on the first lane's stream and brackets that lane's launches:
+    # their average duration while the other lanes' launches overlap them.
+    multi = w['kind'] == 'detect' and pipe is not None and nstreams > 1
+    span_stream = pipe.streams[0] if multi else torch.cuda.current_stream(dev)
+    span_launches = sum(1 for i in range(steps) if (pipe._i + i) % nstreams == 0) if multi else steps
     t0 = time.perf_counter()
     if one_launch_per_step:
-        span[0].record()
+        span[0].record(span_stream)
     for i in range(steps):
-        if w['kind'] == 'detect' and not one_launch_per_step and i in ev:
+        if w['kind'] == 'detect' and not one_launch_per_step and not multi and i in ev:
             last = step(i, ev[i])
         else:
             last = step(i)
     if one_launch_per_step:
-        span[1].record()
+        span[1].record(span_stream)
     enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
@@ -273,12 +289,16 @@ def main():
         if pipe is not None:
             last = pipe.flush()                             # the last batch's select stage (outside the timed region,
                                                             # which selected the last warm-up batch instead)
+            if isinstance(last, list):
+                last = last[-1]
         if last.overflowed():
             raise SystemExit('candidate capacity overflow in the benchmark configuration')
         extra['host_enqueue_ms_per_step'] = round(1e3 * enqueue / steps, 5)
         if one_launch_per_step:
-            kern_ms, n_timed = span[0].elapsed_time(span[1]) / steps, steps
-            timing = 'one HIP event pair around the %d back-to-back launches of the timed region' % steps
+            kern_ms, n_timed = span[0].elapsed_time(span[1]) / span_launches, span_launches
+            timing = ('one HIP event pair around the %d back-to-back launches of the timed region' % steps if not multi else
+                      'one HIP event pair on the first of %d streams around its %d launches of the timed region (the other '
+                      'streams\' launches overlap them)' % (nstreams, span_launches))
         else:
             kern_ms, n_timed = float(np.mean([a.elapsed_time(b) for a, b in ev.values()])), len(ev)
             timing = 'HIP event pairs around every %dth launch of the timed region' % EVENT_EVERY
@@ -308,16 +328,24 @@ def main():
                                           % (ROTATE, B * bytes_img / 1e6), **extra),
         }
         if kern_ms is not None:
-            ach = B * bytes_img / (kern_ms * 1e-3) / 1e9
+            # L streams keep L launches of the kernel in flight together: the bytes a launch accounts for
+            # move in kernel_ms / L on average
+            overlapped = nstreams if multi else 1
+            ach = B * bytes_img / (kern_ms / overlapped * 1e-3) / 1e9
             res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
                                    kernel=detect_kernel_name(args.workload)
                                           + ('; the previous batch\'s NMS stage rides in the same launch)' if one_launch_per_step else ')'),
                                    kernel_ms=round(kern_ms, 5), kernel_launches_timed=n_timed, kernel_timing=timing,
                                    algorithmic_bytes_per_launch=B * bytes_img,
+                                   launches_in_flight=overlapped,
                                    whole_pipeline_frac=round(value / world * bytes_img / 1e9 / HBM_PEAK_GBS, 4))
+            if overlapped > 1:
+                res['roofline']['overlap_note'] = ('%d streams keep %d launches of the kernel in flight together; kernel_ms is the '
+                                                   'average duration of one launch (what a kernel trace shows), achieved and '
+                                                   'traffic_gbs divide it by %d' % (overlapped, overlapped, overlapped))
             if res['roofline']['traffic']:
-                tr = res['roofline']['traffic'] / (kern_ms * 1e-3) / 1e9
+                tr = res['roofline']['traffic'] / (kern_ms / overlapped * 1e-3) / 1e9
                 res['roofline']['traffic_gbs'] = round(tr, 1)
                 res['roofline']['traffic_frac'] = round(tr / HBM_PEAK_GBS, 4)
             if detect_kernel_name(args.workload).startswith('k_detect_rows'):

@@ -201,6 +201,27 @@ def test_pipelined_submit_matches_detect(gpu, cap):
     assert sum(len(g[0][0][0]) for g in got) > 0
 
 
+@pytest.mark.parametrize('lanes', [1, 2, 3])
+def test_lanes_on_several_streams_match_detect(gpu, lanes):
+    """DetectLanes: pipelines on streams of their own, fed in turn; every batch's result is
+    detect()'s, in submission order, whatever the number of lanes."""
+    case = cases.v3()
+    hd = case.head_obj()
+    sets = [y.synth.torch_heads(gpu, 170 + i, 4, case.grids, case.P, case.C) for i in range(7)]
+    want = [hd.detect(h, 0.5, 0.5, 10).per_image() for h in sets]
+    torch.cuda.synchronize()
+    pipe = y.DetectLanes(case.head_obj(), 0.5, 0.5, 10, lanes=lanes)
+    got = []
+    for h in sets:
+        d = pipe.submit(h, wait_current=True)
+        if d is not None:
+            got.append(d.per_image())
+    got += [d.per_image() for d in pipe.flush()]
+    assert len(got) == len(want) and pipe.flush() == []
+    for g, w in zip(got, want):
+        cases.same_detections(g, w)
+
+
 def test_candidates_then_select_calls(gpu):
     """The two halves of yh_detect called one after the other through the C ABI."""
     import ctypes

@@ -397,8 +397,9 @@ class DetectPipeline:
     has to be submitted again to a pipeline with a larger max_candidates."""
 
     def __init__(self, head, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-                 want_class_candidates=False, stream=None):
+                 want_class_candidates=False, stream=None, tag=0):
         self.head = head
+        self.tag = tag             # keeps the workspaces of several pipelines on one head apart
         self.thr, self.iou, self.max_boxes = float(score_threshold), float(iou_threshold), int(max_boxes)
         self.cap = max_candidates
         self.want_cc = want_class_candidates
@@ -424,7 +425,7 @@ class DetectPipeline:
         N = hd.boxes_per_image(heads)
         cap = int(self.cap) if self.cap is not None else hd.default_max_candidates(N)
         slot = self._i & 1
-        cfg, B, N, ws = hd._detect_plan(heads, cap, self.max_boxes, slot=('pipe', slot))
+        cfg, B, N, ws = hd._detect_plan(heads, cap, self.max_boxes, slot=('pipe', self.tag, slot))
         prev = self._prev
         if prev is not None and (prev[1] != B or prev[5] != cap or bytes(prev[0]) != bytes(cfg)):
             raise ValueError('a pipeline takes equally shaped batches; flush() before changing shape')
@@ -451,3 +452,46 @@ class DetectPipeline:
             _abi.check(lib.yh_detect_pipelined(*args))
         self._prev = None
         return Detections(*outputs, None)
+
+
+class DetectLanes:
+    """Several DetectPipelines on streams of their own, fed in turn: the tail of a
+    launch (the few surviving rows: latency-bound, little data) overlaps the start
+    of the next lane's launch (the objectness column: bandwidth-bound), which one
+    stream cannot do because its launches run one after the other.
+    submit(heads) returns the Detections of the batch submitted `lanes` * 1 calls
+    earlier on the same lane (None at first); flush() returns the outstanding ones
+    in submission order.  The head tensors must be complete as far as the lane's
+    stream can tell: produce them on `stream_of_next()`, or pass wait_current=True
+    to make the lane wait for the caller's current stream (an event record and a
+    stream wait per submit)."""
+
+    def __init__(self, head, score_threshold, iou_threshold, max_boxes, lanes=2, max_candidates=None,
+                 want_class_candidates=False, device=None):
+        if lanes < 1:
+            raise ValueError('at least one lane')
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        self.streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        self.pipes = [DetectPipeline(head, score_threshold, iou_threshold, max_boxes, max_candidates,
+                                     want_class_candidates, stream=s, tag=('lane', i))
+                      for i, s in enumerate(self.streams)]
+        self._i = 0
+
+    def stream_of_next(self):
+        return self.streams[self._i % len(self.streams)]
+
+    def submit(self, heads, wait_current=False):
+        lane = self._i % len(self.pipes)
+        if wait_current:
+            self.streams[lane].wait_stream(torch.cuda.current_stream(heads[0].device))
+        self._i += 1
+        return self.pipes[lane].submit(heads)
+
+    def flush(self):
+        n = len(self.pipes)
+        order = [(self._i + k) % n for k in range(n)]          # oldest outstanding batch first
+        return [d for d in (self.pipes[lane].flush() for lane in order) if d is not None]
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

@@ -225,8 +225,9 @@ def main():
                 out, _grads = hd.loss_and_grad(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True,
                                                grad_scale=0.5 / y.parallel.global_batch(B))
                 return y.parallel.global_mean_loss(out['sum'], B, out['mean'])
-            out = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
+            out = reuse['out'] = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
             return y.parallel.global_mean_loss(out['sum'], B, out['mean'])   # the data-parallel scalar all-reduce
+        reuse = {}                                           # the loss outputs are written in place step after step
         extra = {}
         if w.get('backward'):
             for i in range(5):

@@ -463,6 +463,23 @@ def test_loss_and_grad_equals_the_autograd_path(gpu):
         assert torch.equal(g, l.grad)
 
 
+def test_loss_outputs_can_be_reused(gpu):
+    """loss(out=previous result) writes the same tensors again and gives the fresh call's values."""
+    case = cases.v3(size=96)
+    hd = case.head_obj()
+    gt = torch.from_numpy(y.synth.make_ground_truth(95, 2, 4, 7, 96, case.C)).to(gpu)
+    a = to_dev(case.heads(93, 2), gpu)
+    b = to_dev(case.heads(94, 2), gpu)
+    first = hd.loss(a, gt, 1., 1., 5., 1., 0.5, True, want_mask=True)
+    keep = {k: v.clone() for k, v in hd.loss(b, gt, 1., 1., 5., 1., 0.5, True, want_mask=True).items() if v is not None}
+    again = hd.loss(b, gt, 1., 1., 5., 1., 0.5, True, want_mask=True, out=first)
+    assert again is first and again['per_image'].data_ptr() == first['per_image'].data_ptr()
+    for k in ('per_image', 'sum', 'mean', 'noobj_mask'):
+        assert torch.equal(again[k], keep[k])
+    other = hd.loss(b, gt, 1., 1., 5., 1., 0.5, True, want_parts=True, out=first)       # different options: fresh tensors
+    assert other is not first and other['parts'] is not None
+
+
 def test_loss_backward_is_the_derivative_of_the_forward(gpu):
     """Directional finite difference of the GPU loss itself (fp32 forward evaluated at
     +-eps along a random direction) against <grad, direction>: 1e-3, the resolution of

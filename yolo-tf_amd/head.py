@@ -117,8 +117,14 @@ class DetectionHead:
         return out
 
     def config_for(self, heads):
-        grids = [(int(h.shape[1]), int(h.shape[2])) for h in heads]
-        return make_config(grids, self.priors, self.box_mult, self.gt_rate, self.num_classes)
+        grids = tuple((int(h.shape[1]), int(h.shape[2])) for h in heads)
+        cfg = self._configs.get(grids) if hasattr(self, '_configs') else None
+        if cfg is None:
+            if not hasattr(self, '_configs'):
+                self._configs = {}
+            cfg = self._configs[grids] = make_config(list(grids), self.priors, self.box_mult, self.gt_rate,
+                                                     self.num_classes)
+        return cfg
 
     def boxes_per_image(self, heads):
         return sum(int(h.shape[1]) * int(h.shape[2]) * self.num_priors for h in heads)
@@ -274,12 +280,16 @@ class DetectionHead:
 
     # --------------------------------------------------------------- loss
     def loss(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
-             ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False):
+             ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False,
+             out=None):
         """Per-image training loss (YOLOv3.py:117-310 / YOLOv2.py:105-173).
         ground_truth: [B, pad, 5] float32 CUDA tensor, -1 padded.
         Returns dict(per_image [B], sum [1], mean [1] (sum / B), parts [B,4] | None, iou_max [B,N] | None,
         noobj_mask [B,N] uint8 | None: what loss_backward needs).  No autograd
-        graph is recorded here: loss_with_grad does that."""
+        graph is recorded here: loss_with_grad does that.  out: the dict of an
+        earlier call with the same shapes and options, whose tensors are then
+        written again instead of new ones being allocated (a tight loop saves the
+        allocations' host time)."""
         lib = _abi.load()
         heads = self._check_heads(heads)
         cfg = self.config_for(heads)
@@ -291,14 +301,23 @@ class DetectionHead:
         if gt.dim() != 3 or gt.shape[0] != B or gt.shape[2] != 5:
             raise ValueError('ground_truth must be [B, pad, 5]')
         pad = int(gt.shape[1])
-        nbytes = ctypes.c_size_t(0)
-        _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
-        ws = self._workspace(('loss', B, N, pad), nbytes.value, dev)
-        per = torch.empty((B,), dtype=torch.float32, device=dev)
-        total = torch.empty((2,), dtype=torch.float32, device=dev)      # sum, mean over this call's images
-        parts = torch.empty((B, 4), dtype=torch.float32, device=dev) if want_parts else None
-        iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
-        mask = torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None
+        ws = self._ws.get(('loss', B, N, pad))
+        if ws is None or ws.device != dev:
+            nbytes = ctypes.c_size_t(0)
+            _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
+            ws = self._workspace(('loss', B, N, pad), nbytes.value, dev)
+        if (out is not None and out['per_image'].shape == (B,) and out['per_image'].device == dev and
+                (out['parts'] is not None) == want_parts and (out['iou_max'] is not None) == want_iou_max and
+                (out['noobj_mask'] is not None) == want_mask and
+                (not want_mask or out['noobj_mask'].shape == (B, N)) and (not want_iou_max or out['iou_max'].shape == (B, N))):
+            per, total, parts, iou, mask = out['per_image'], out['_total'], out['parts'], out['iou_max'], out['noobj_mask']
+        else:
+            out = None
+            per = torch.empty((B,), dtype=torch.float32, device=dev)
+            total = torch.empty((2,), dtype=torch.float32, device=dev)      # sum, mean over this call's images
+            parts = torch.empty((B, 4), dtype=torch.float32, device=dev) if want_parts else None
+            iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
+            mask = torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None
         scales = (ctypes.c_float * 4)(float(coord_scale), float(noobj_scale), float(obj_scale), float(class_scale))
         with torch.cuda.device(dev):
             _abi.check(lib.yh_loss_forward(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
@@ -307,7 +326,9 @@ class DetectionHead:
                                            per.data_ptr(), parts.data_ptr() if want_parts else None,
                                            iou.data_ptr() if want_iou_max else None, total.data_ptr(),
                                            mask.data_ptr() if want_mask else None, self._stream(dev)))
-        return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask)
+        if out is not None:
+            return out
+        return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask, _total=total)
 
     def loss_backward(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                       normalize_by_num_gt, noobj_mask, grad_per_image):

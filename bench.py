@@ -187,8 +187,7 @@ def main():
         # --in-flight 1 runs every batch to completion before the next (yh_detect).
         lanes = 2 if args.in_flight > 1 else 1
         outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
-        # several streams only where a step is one launch (small candidate capacity)
-        nstreams = max(1, args.streams) if (lanes > 1 and args.workload != 'stress') else 1
+        nstreams = max(1, args.streams) if lanes > 1 else 1
         pipe = None
         if lanes > 1:
             pipe = (y.DetectLanes(hd, w['thr'], w['iou'], w['max_boxes'], lanes=nstreams, device=dev) if nstreams > 1
@@ -318,6 +317,19 @@ def main():
         elif one_launch_per_step:
             kern_ms, n_timed = span[0].elapsed_time(span[1]) / span_launches, span_launches
             timing = 'one HIP event pair around the %d back-to-back launches of the timed region' % steps
+        elif multi:
+            # several launches per step and several streams: the dominant kernel on its own, from event
+            # pairs around every 10th launch of a single-stream section right after the timed region
+            solo = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes'], tag='solo')
+            for i in range(5):
+                solo.submit(sets[i % ROTATE])
+            for i in range(steps):
+                solo.submit(sets[i % ROTATE], stream_events=ev.get(i))
+            torch.cuda.synchronize(dev)
+            solo.flush()
+            kern_ms, n_timed = float(np.mean([a.elapsed_time(b) for a, b in ev.values()])), len(ev)
+            timing = ('HIP event pairs around every %dth launch of a single-stream section right after the timed region '
+                      '(whose steps overlap across %d streams)' % (EVENT_EVERY, nstreams))
         else:
             kern_ms, n_timed = float(np.mean([a.elapsed_time(b) for a, b in ev.values()])), len(ev)
             timing = 'HIP event pairs around every %dth launch of the timed region' % EVENT_EVERY

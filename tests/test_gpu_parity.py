@@ -171,11 +171,13 @@ def test_both_launch_shapes_agree(gpu, c_oracle):
             cases.same_detections(got.per_image(), want)
 
 
-@pytest.mark.parametrize('cap', [None, 2048, 5000])
-def test_pipelined_submit_matches_detect(gpu, cap):
+@pytest.mark.parametrize('cap,kernel', [(None, '1'), (2048, '1'), (5000, '1'), (None, '2'), (2048, '2')])
+def test_pipelined_submit_matches_detect(gpu, monkeypatch, cap, kernel):
     """yh_detect_pipelined: batch i streams while batch i-1 is selected inside the same
     launch (capacity 512), or right before it (larger capacities): detect()'s results,
-    batch after batch, on alternating workspaces."""
+    batch after batch, on alternating workspaces; with the objectness-first kernel (1) and
+    with the streaming one (2)."""
+    monkeypatch.setenv('YH_DETECT_KERNEL', kernel)
     case = cases.v3()
     hd = case.head_obj()
     sets = [y.synth.torch_heads(gpu, 70 + i, 4, case.grids, case.P, case.C) for i in range(5)]

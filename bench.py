@@ -141,8 +141,8 @@ def load_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='detect416', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='images per GPU (default: the workload\'s)')
     ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
@@ -271,6 +271,9 @@ def main():
     multi = w['kind'] == 'detect' and pipe is not None and nstreams > 1
     span_stream = pipe.streams[0] if multi else torch.cuda.current_stream(dev)
     span_launches = sum(1 for i in range(steps) if (pipe._i + i) % nstreams == 0) if multi else steps
+    import gc
+    gc.collect()
+    gc.disable()                                            # no collector pause inside the few-millisecond timed region
     t0 = time.perf_counter()
     if one_launch_per_step:
         span[0].record(span_stream)
@@ -284,6 +287,7 @@ def main():
     enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     if w['kind'] == 'detect':
         if pipe is not None:
@@ -304,16 +308,23 @@ def main():
             solo = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes'], tag='solo')
             for i in range(10):
                 solo.submit(sets[i % ROTATE])
-            n_timed = max(50, steps // 2)
-            span[0].record()
-            for i in range(n_timed):
-                solo.submit(sets[i % ROTATE])
-            span[1].record()
-            torch.cuda.synchronize(dev)
+            # five runs of back-to-back launches, each under its own event pair; the median run counts (a
+            # run in which the host falls behind with enqueueing would time the host, not the kernel)
+            per_run, runs = max(40, min(200, steps // 5)), []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for i in range(per_run):
+                    solo.submit(sets[i % ROTATE])
+                b.record()
+                torch.cuda.synchronize(dev)
+                runs.append(a.elapsed_time(b) / per_run)
             solo.flush()
-            kern_ms = span[0].elapsed_time(span[1]) / n_timed
-            timing = ('one HIP event pair around %d back-to-back launches on one stream, right after the timed region '
-                      '(whose launches overlap across %d streams: kernel_ms_overlapped)' % (n_timed, nstreams))
+            kern_ms, n_timed = float(np.median(runs)), 5 * per_run
+            extra['kernel_ms_runs'] = [round(r, 5) for r in runs]
+            timing = ('HIP event pairs around 5 runs of %d back-to-back launches on one stream right after the timed region '
+                      '(median run; the timed region\'s launches overlap across %d streams: kernel_ms_overlapped)'
+                      % (per_run, nstreams))
         elif one_launch_per_step:
             kern_ms, n_timed = span[0].elapsed_time(span[1]) / span_launches, span_launches
             timing = 'one HIP event pair around the %d back-to-back launches of the timed region' % steps

@@ -203,6 +203,36 @@ def test_pipelined_submit_matches_detect(gpu, monkeypatch, cap, kernel):
     assert sum(len(g[0][0][0]) for g in got) > 0
 
 
+def test_pipeline_keeps_up_with_changing_batches(gpu):
+    """A pipeline prepares its call once per slot and reuses it while batches keep their
+    shape; batches of another size (after a flush), a return to the first size, and a
+    strided head tensor in between all give detect()'s results."""
+    case = cases.v3()
+    hd = case.head_obj()
+    pipe = y.DetectPipeline(case.head_obj(), 0.5, 0.5, 10)
+    seed = 300
+    for B, n in ((4, 4), (2, 1), (4, 3), (3, 4)):
+        sets = [y.synth.torch_heads(gpu, seed + i, B, case.grids, case.P, case.C) for i in range(n)]
+        seed += n
+        if n >= 3:                                   # same values behind a non-contiguous view
+            wide = torch.zeros(tuple(sets[2][1].shape[:3]) + (2 * sets[2][1].shape[3],), device=gpu)
+            wide[..., ::2] = sets[2][1]
+            sets[2] = [sets[2][0], wide[..., ::2], sets[2][2]]
+            assert not sets[2][1].is_contiguous()
+        want = [hd.detect(h, 0.5, 0.5, 10).per_image() for h in sets]
+        got = []
+        for h in sets:
+            d = pipe.submit(h)
+            if d is not None:
+                got.append(d.per_image())
+        got.append(pipe.flush().per_image())
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            cases.same_detections(g, w)
+            for a, b in zip(g, w):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 @pytest.mark.parametrize('lanes', [1, 2, 3])
 def test_lanes_on_several_streams_match_detect(gpu, lanes):
     """DetectLanes: pipelines on streams of their own, fed in turn; every batch's result is

@@ -428,6 +428,7 @@ class DetectPipeline:
         self._i = 0
         self._prev = None          # (cfg, B, workspace, outputs, device) of the batch awaiting its select stage
         self._outputs = [None, None]
+        self._steady = [None, None]    # per slot: the prepared call of a batch shaped like the last one
 
     def _args(self, cfg, head_ptrs, B, cap, ws, prev_ws, nbytes, outputs, dev, events):
         ev = events or (None, None)
@@ -438,10 +439,55 @@ class DetectPipeline:
                 st, ctypes.c_void_p(ev[0].cuda_event) if ev[0] is not None else None,
                 ctypes.c_void_p(ev[1].cuda_event) if ev[1] is not None else None]
 
+    def _submit_steady(self, heads):
+        """The call of submit() for a batch shaped like the last one on this slot, with
+        everything but the head pointers prepared by that earlier call; None when the
+        batch has to take the checked path."""
+        slot = self._i & 1
+        rec = self._steady[slot]
+        prev = self._prev
+        if rec is None or prev is None:
+            return None
+        shapes, dev, cap, prev_ws, prev_outputs, args, arr, mine, default_for = rec
+        # the prepared arguments hold the addresses of exactly these tensors
+        if prev[2] is not prev_ws or prev[3] is not prev_outputs or self._outputs[slot] is not mine[3]:
+            return None
+        if len(heads) != len(shapes):
+            return None
+        if self.stream is None:
+            args[-3] = self.head._stream(dev)
+        for k, h in enumerate(heads):
+            if not (isinstance(h, torch.Tensor) and h.shape == shapes[k] and h.dtype is torch.float32
+                    and h.device == dev and h.is_contiguous()):
+                return None
+            arr[k] = h.data_ptr()
+        if self.cap is None and self.head.default_max_candidates(default_for) != cap:
+            return None
+        lib = _abi.load()
+        if torch.cuda.current_device() == dev.index:
+            _abi.check(lib.yh_detect_pipelined(*args))
+        else:
+            with torch.cuda.device(dev):
+                _abi.check(lib.yh_detect_pipelined(*args))
+        done = Detections(*prev[3], None)
+        self._prev = mine
+        self._i += 1
+        return done
+
     def submit(self, heads, stream_events=None):
+        if stream_events is None:
+            done = self._submit_steady(heads)
+            if done is not None:
+                return done
         lib = _abi.load()
         hd = self.head
+        given = heads
         heads = hd._check_heads(heads)
+        if self.stream is not None:
+            for h, g in zip(heads, given):
+                if h is not g:                       # a packed copy made here: it is read on the pipeline's stream
+                    self.stream.wait_stream(torch.cuda.current_stream(h.device))
+                    h.record_stream(self.stream)
         dev = heads[0].device
         N = hd.boxes_per_image(heads)
         cap = int(self.cap) if self.cap is not None else hd.default_max_candidates(N)
@@ -452,13 +498,17 @@ class DetectPipeline:
             raise ValueError('a pipeline takes equally shaped batches; flush() before changing shape')
         if self._outputs[slot] is None or self._outputs[slot][0].shape[0] != B:
             self._outputs[slot] = hd._alloc_outputs(B, self.max_boxes, dev, self.want_cc)
-        args = self._args(cfg, _abi.pointer_array([h.data_ptr() for h in heads]), B, cap, ws.data_ptr(),
+        arr = _abi.pointer_array([h.data_ptr() for h in heads])
+        args = self._args(cfg, arr, B, cap, ws.data_ptr(),
                           prev[2].data_ptr() if prev is not None else None, ws.numel(),
                           prev[3] if prev is not None else None, dev, stream_events)
         with torch.cuda.device(dev):
             _abi.check(lib.yh_detect_pipelined(*args))
         done = Detections(*prev[3], None) if prev is not None else None
         self._prev = (cfg, B, ws, self._outputs[slot], dev, cap)
+        if prev is not None and stream_events is None:
+            self._steady[slot] = (tuple(h.shape for h in heads), dev, cap, prev[2], prev[3], args, arr,
+                                  self._prev, N)
         self._i += 1
         return done
 
@@ -485,7 +535,8 @@ class DetectLanes:
     in submission order.  The head tensors must be complete as far as the lane's
     stream can tell: produce them on `stream_of_next()`, or pass wait_current=True
     to make the lane wait for the caller's current stream (an event record and a
-    stream wait per submit)."""
+    stream wait per submit).  Keep a batch's head tensors alive until its
+    Detections have been returned: the lane's launch reads them asynchronously."""
 
     def __init__(self, head, score_threshold, iou_threshold, max_boxes, lanes=2, max_candidates=None,
                  want_class_candidates=False, device=None):

@@ -95,6 +95,7 @@ class DetectionHead:
         self.box_mult = [float(m) for m in box_mult]
         self.gt_rate = [float(r) for r in gt_rate]
         self._ws = {}
+        self._configs = {}
         self._plans = {}
         self._grown = {}
 
@@ -118,10 +119,8 @@ class DetectionHead:
 
     def config_for(self, heads):
         grids = tuple((int(h.shape[1]), int(h.shape[2])) for h in heads)
-        cfg = self._configs.get(grids) if hasattr(self, '_configs') else None
+        cfg = self._configs.get(grids)
         if cfg is None:
-            if not hasattr(self, '_configs'):
-                self._configs = {}
             cfg = self._configs[grids] = make_config(list(grids), self.priors, self.box_mult, self.gt_rate,
                                                      self.num_classes)
         return cfg

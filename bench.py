@@ -220,7 +220,7 @@ def main():
 
         def step(i, events=None):
             if w.get('backward'):
-                # forward + backward as two library calls: d(.5 * mean loss) / d(head) for every head
+                # forward + backward in one library call: d(.5 * mean loss) / d(head) for every head
                 out, _grads = hd.loss_and_grad(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True,
                                                grad_scale=0.5 / y.parallel.global_batch(B))
                 return y.parallel.global_mean_loss(out['sum'], B, out['mean'])
@@ -237,8 +237,9 @@ def main():
                 step_autograd(i)
             torch.cuda.synchronize(dev)
             extra = {'through_autograd_ms_per_step': round((time.perf_counter() - t0) / 30 * 1e3, 5),
-                     'note': 'timed: loss_and_grad (two library calls); through_autograd = the same step via '
-                             'torch.autograd (loss_with_grad + backward()), host-bound by the engine'}
+                     'note': 'timed: loss_and_grad (yh_loss_with_grad: the gradient tensor is filled during the '
+                             'forward pass); through_autograd = the same step via torch.autograd '
+                             '(loss_with_grad + backward(): forward, then backward), host-bound by the engine'}
 
     def barrier():
         torch.cuda.synchronize(dev)

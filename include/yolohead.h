@@ -246,6 +246,19 @@ int yh_loss_backward(const yh_head_config *cfg, const float *const *heads, const
                      const uint8_t *noobj_mask, const float *grad_per_image, float *const *grad_heads,
                      void *stream);
 
+/* Both at once, for a training step whose upstream gradient is known before the
+ * forward pass (grad_per_image [B]: the constant 1/batch of `reduce_mean`,
+ * YOLOv3.py:311-318, times any loss scaling): yh_loss's outputs and
+ * yh_loss_backward's grad_heads from one pass over the rows.  The gradient
+ * tensor's zeros are written while the ignore-mask loop computes, instead of by a
+ * launch of their own afterwards; results are those of yh_loss_forward followed
+ * by yh_loss_backward, bit for bit.  grad_heads must not alias heads. */
+int yh_loss_with_grad(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                      int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                      int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                      float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                      const float *grad_per_image, float *const *grad_heads, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -495,6 +495,35 @@ def test_loss_and_grad_equals_the_autograd_path(gpu):
         assert torch.equal(g, l.grad)
 
 
+@pytest.mark.parametrize('version,size,B,G,pad,exact', [
+    ('v3', 416, 8, 60, 100, False), ('v3', 96, 3, 0, 3, False), ('v3', 160, 2, 5, 30, True),
+    ('v2', 416, 4, 1, 20, False), ('v3', 608, 2, 99, 100, False)])
+def test_fused_loss_and_gradient_equal_the_two_calls(gpu, version, size, B, G, pad, exact):
+    """yh_loss_with_grad (gradient written during the forward pass) against yh_loss_forward
+    followed by yh_loss_backward: every output bit for bit, with few and many ground-truth
+    rows (zeros written inside and after the ignore-mask loop), with the IoU maxima, v2 and v3."""
+    case = cases.v3(size=size) if version == 'v3' else cases.v2()
+    pix = size if version == 'v3' else 416
+    norm, thr = (True, 0.5) if version == 'v3' else (False, 0.6)
+    heads = y.synth.torch_heads(gpu, 401, B, case.grids, case.P, case.C, obj_mean=-1.0)
+    gt = torch.from_numpy(y.synth.make_ground_truth(402, B, G, pad, pix, case.C)).to(gpu)
+    hd = case.head_obj()
+    gw = torch.linspace(0.25, 1.5, B, device=gpu)
+    two = hd.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, want_mask=True)
+    want = hd.loss_backward(heads, gt, 1., 0.5, 5., 2., norm, two['noobj_mask'], gw)
+    poison = [torch.full_like(w, float('nan')) for w in want]   # freed blocks the allocator hands out next:
+    del poison                                                  # the fused pass must overwrite all of them
+    one = hd.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, grad_per_image=gw)
+    def same(a, b):                                  # NaN where the reference divides by a GT count of zero
+        return a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=7e30, neginf=-7e30),
+                                                  torch.nan_to_num(b, nan=-7.0, posinf=7e30, neginf=-7e30))
+    for k in ('per_image', 'sum', 'mean', 'parts') + (('iou_max',) if exact else ()):
+        assert same(one[k], two[k]), k
+    for s, (g, w) in enumerate(zip(one['grads'], want)):
+        assert same(g, w), s
+    assert sum(int((g != 0).sum()) for g in one['grads']) > 0
+
+
 def test_loss_outputs_can_be_reused(gpu):
     """loss(out=previous result) writes the same tensors again and gives the fresh call's values."""
     case = cases.v3(size=96)

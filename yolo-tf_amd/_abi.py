@@ -74,6 +74,8 @@ SIGNATURES = {
     'yh_loss_forward': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _F, _I, _P, ctypes.c_size_t,
                                        _P, _P, _P, _P, _P, _P]),
     'yh_loss_backward': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _I, _P, _P, _PP, _P]),
+    'yh_loss_with_grad': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _F, _I, _P, ctypes.c_size_t,
+                                         _P, _P, _P, _P, _P, _PP, _P]),
     'yh_loss': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _F, _I, _P, ctypes.c_size_t,
                                _P, _P, _P, _P, _P]),
 }

@@ -696,11 +696,21 @@ int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pa
     return YH_OK;
 }
 
-int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
-                    int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
-                    int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
-                    float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
-                    uint8_t *noobj_mask, void *stream)
+static int check_grad_heads(const yh_head_config *cfg, const float *const *heads, float *const *grad_heads)
+{
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        if (!grad_heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] is null", s);
+        if (grad_heads[s] == heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] aliases heads[%d]", s, s);
+    }
+    return YH_OK;
+}
+
+// The forward pass; with grad_per_image and grad_heads, the gradient in the same pass.
+static int loss_forward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                        int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                        int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                        float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                        uint8_t *noobj_mask, const float *grad_per_image, float *const *grad_heads, void *stream)
 {
     int rc = check_config(cfg);
     if (rc != YH_OK) return rc;
@@ -710,6 +720,7 @@ int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const 
     if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
     if (!ground_truth || !workspace || !loss_per_image)
         return fail(YH_ERR_INVALID_ARG, "null ground_truth, workspace or loss_per_image");
+    if (grad_per_image && (rc = check_grad_heads(cfg, heads, grad_heads)) != YH_OK) return rc;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail(YH_ERR_ALIGN, "workspace is not 256-byte aligned");
     yh::LossParams p;
     plan_loss(p, cfg, batch, pad);
@@ -717,7 +728,8 @@ int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const 
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
-    for (int s = 0; s < p.S; ++s) p.sc[s].head = heads[s];
+    for (int s = 0; s < p.S; ++s) { p.sc[s].head = heads[s]; p.sc[s].grad = grad_per_image ? grad_heads[s] : nullptr; }
+    p.grad_w = grad_per_image;
     p.w_coord = loss_scales[0]; p.w_noobj = loss_scales[1]; p.w_obj = loss_scales[2]; p.w_class = loss_scales[3];
     p.ignore_thr = ignore_threshold;
     p.normalize = normalize_by_num_gt ? 1 : 0;
@@ -730,14 +742,38 @@ int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const 
     return YH_OK;
 }
 
+int yh_loss_forward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                    int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                    int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                    float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                    uint8_t *noobj_mask, void *stream)
+{
+    return loss_forward(cfg, heads, ground_truth, batch, pad, loss_scales, ignore_threshold, normalize_by_num_gt,
+                        workspace, workspace_bytes, loss_per_image, loss_parts, iou_max, loss_sum, noobj_mask,
+                        nullptr, nullptr, stream);
+}
+
 int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
             int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
             int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
             float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
             void *stream)
 {
-    return yh_loss_forward(cfg, heads, ground_truth, batch, pad, loss_scales, ignore_threshold, normalize_by_num_gt,
-                           workspace, workspace_bytes, loss_per_image, loss_parts, iou_max, loss_sum, nullptr, stream);
+    return loss_forward(cfg, heads, ground_truth, batch, pad, loss_scales, ignore_threshold, normalize_by_num_gt,
+                        workspace, workspace_bytes, loss_per_image, loss_parts, iou_max, loss_sum, nullptr,
+                        nullptr, nullptr, stream);
+}
+
+int yh_loss_with_grad(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
+                      int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
+                      int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,
+                      float *loss_per_image, float *loss_parts, float *iou_max, float *loss_sum,
+                      const float *grad_per_image, float *const *grad_heads, void *stream)
+{
+    if (!grad_per_image || !grad_heads) return fail(YH_ERR_INVALID_ARG, "null grad_per_image or grad_heads");
+    return loss_forward(cfg, heads, ground_truth, batch, pad, loss_scales, ignore_threshold, normalize_by_num_gt,
+                        workspace, workspace_bytes, loss_per_image, loss_parts, iou_max, loss_sum, nullptr,
+                        grad_per_image, grad_heads, stream);
 }
 
 int yh_loss_backward(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
@@ -753,10 +789,7 @@ int yh_loss_backward(const yh_head_config *cfg, const float *const *heads, const
     if ((rc = check_heads(cfg, heads)) != YH_OK) return rc;
     if (!ground_truth || !noobj_mask || !grad_per_image || !grad_heads)
         return fail(YH_ERR_INVALID_ARG, "null ground_truth, noobj_mask, grad_per_image or grad_heads");
-    for (int s = 0; s < cfg->num_scales; ++s) {
-        if (!grad_heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] is null", s);
-        if (grad_heads[s] == heads[s]) return fail(YH_ERR_INVALID_ARG, "grad_heads[%d] aliases heads[%d]", s, s);
-    }
+    if ((rc = check_grad_heads(cfg, heads, grad_heads)) != YH_OK) return rc;
     if ((rc = ensure_device()) != YH_OK) return rc;
     yh::LossParams p;
     plan_loss(p, cfg, batch, pad);

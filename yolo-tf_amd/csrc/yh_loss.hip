@@ -110,7 +110,14 @@ __device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int
 // involved, and its negation likewise; a box with a pair inside the margin, or
 // with a zero or non-finite union, is walked again with the division.  Same
 // decisions, less arithmetic.
-template <bool EXACT_MAX>
+//
+// GRAD = true: the workgroup also writes its rows of the gradient tensor (what
+// k_loss_grad_fill writes: zeros, and the no-object term in the objectness column).  The
+// zeros are 16-byte stores spread over the IoU loop, one every other step, so the memory
+// system drains them while the loop keeps the vector units busy (the loop is compute-bound,
+// the fill is write-bound); lanes that skip the loop catch up after it; the objectness
+// column follows once the mask is known, behind the barrier that orders it after the zeros.
+template <bool EXACT_MAX, bool GRAD>
 __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw,
                                                float *s_val, int *s_idx)
 {
@@ -170,7 +177,28 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     float obj = 0.0f;
     if (in_range) obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
 
+    // the workgroup's run of the gradient tensor: `lead` single floats up to 16-byte alignment,
+    // nb 16-byte blocks, then fewer than four single floats
+    const uint32_t row0 = (r - sc.blk_begin) * kLossNegThreads;
+    float *gdst = nullptr;
+    float4 *gdst4 = nullptr;
+    uint32_t gtotal = 0, lead = 0, nb = 0, filled = 0;
+    float gscale = 0.0f;
+    if (GRAD) {
+        const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegThreads ? sc.rows_img - row0 : (uint32_t)kLossNegThreads;
+        gdst = sc.grad + ((long long)b * sc.rows_img + row0) * K;
+        gtotal = nrows * (uint32_t)K;
+        lead = (4u - (uint32_t)((reinterpret_cast<uintptr_t>(gdst) >> 2) & 3u)) & 3u;
+        lead = lead < gtotal ? lead : gtotal;
+        nb = (gtotal - lead) >> 2;
+        gdst4 = reinterpret_cast<float4 *>(gdst + lead);
+        gscale = p.w_noobj * p.grad_w[b];
+        if (p.normalize) gscale = gscale / (float)G;
+    }
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
     float contrib = 0.0f;
+    bool counted_row = false;
     if (in_range) {
         const uint32_t cell = row / (uint32_t)P;
         const uint32_t pi = row - cell * (uint32_t)P;
@@ -224,6 +252,11 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                 const f2 nthr = {-thr, -thr}, mf = {mfac, mfac}, tiny = {0x1p-100f, 0x1p-100f};
                 const f2 aa = {aarea, aarea};
                 for (int j = 0; j < pairs; ++j) {
+                    if (GRAD && !(j & 1)) {
+                        const uint32_t i = filled * (uint32_t)kLossNegThreads + (uint32_t)tid;
+                        if (i < nb) gdst4[i] = zero4;
+                        ++filled;
+                    }
                     const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'
                     const float4 hi = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride + 4);  // y2 y2' x2 x2'
                     const float2 ar = *reinterpret_cast<const float2 *>(s_pair + j * kPairStride + 8);
@@ -257,6 +290,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             }
         }
         if (counted) contrib = sigmoid_ce(obj, 0.0f);
+        counted_row = counted;
         if (EXACT_MAX) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
         if (p.noobj_mask) p.noobj_mask[(long long)b * p.N + sc.row_base + row] = counted ? 1 : 0;
     }
@@ -265,7 +299,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
     if ((tid & 63) == 0) s_val[tid >> 6] = contrib;
+    if (GRAD) {                                                 // the zeros the loop above did not get to
+        for (uint32_t i = filled * (uint32_t)kLossNegThreads + (uint32_t)tid; i < nb; i += kLossNegThreads) gdst4[i] = zero4;
+        if ((uint32_t)tid < lead) gdst[tid] = 0.0f;
+        const uint32_t e = lead + 4u * nb + (uint32_t)tid;
+        if (e < gtotal) gdst[e] = 0.0f;
+    }
     __syncthreads();
+    if (GRAD && counted_row) gdst[(row - row0) * (uint32_t)K + (uint32_t)(C + 4)] = sigmoidf(obj) * gscale;
     if (tid == 0) {
         float acc = s_val[0];
         for (int w = 1; w < kLossNegThreads / 64; ++w) acc += s_val[w];
@@ -404,7 +445,7 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
 // One launch for both branches: the last B * pos_blocks workgroups take the
 // positive branch (short, latency-bound: they fill in behind the negative ones).
 static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
-template <bool EXACT_MAX>
+template <bool EXACT_MAX, bool GRAD>
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
 {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -412,18 +453,17 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
     __shared__ int s_idx[kLossNegThreads / 64];
     __shared__ float s_part[kLossNegThreads / 64][3];
     const uint32_t nneg = (uint32_t)p.B * (uint32_t)p.blocks_per_img;
-    if (blockIdx.x < nneg) loss_neg_block<EXACT_MAX>(p, blockIdx.x, s_raw, s_val, s_idx);
+    if (blockIdx.x < nneg) loss_neg_block<EXACT_MAX, GRAD>(p, blockIdx.x, s_raw, s_val, s_idx);
     else loss_pos_block(p, blockIdx.x - nneg, s_val, s_idx, s_part);
 }
 
 // ---------------------------------------------------------------- finalize
 // One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
-// the batch sum.  Sixteen lanes per image (64 images at a time): they fetch the
-// image's partial sums together and add them up in double in a fixed tree, so the
-// result does not depend on scheduling.
+// the batch sum.  Sixteen lanes per image (64 images at a time with 1024 threads): they
+// fetch the image's partial sums together and add them up in double in a fixed tree, so
+// the result depends neither on scheduling nor on the workgroup's size.
 constexpr int kFinalizeThreads = 1024;
 constexpr int kFinalizeLanes = 16;
-constexpr int kFinalizeGroups = kFinalizeThreads / kFinalizeLanes;
 
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -432,9 +472,10 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
-__global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
+template <int THREADS>
+__device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum)
 {
-    __shared__ double s_sum[kFinalizeGroups];
+    constexpr int kFinalizeGroups = THREADS / kFinalizeLanes;
     const int tid = threadIdx.x, gl = tid & (kFinalizeLanes - 1), grp = tid / kFinalizeLanes;
     double local = 0.0;                                        // lane 0 of each group: its images' losses
     for (int b = grp; b < p.B; b += kFinalizeGroups) {
@@ -467,6 +508,12 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossPa
         p.loss_sum[0] = (float)acc;
         p.loss_sum[1] = (float)acc / (float)p.B;              // reduce_mean over this call's images, in fp32
     }
+}
+
+__global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
+{
+    __shared__ double s_sum[kFinalizeThreads / kFinalizeLanes];
+    loss_finalize<kFinalizeThreads>(p, s_sum);
 }
 
 // ---------------------------------------------------------------- backward
@@ -540,13 +587,11 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossPa
 
 // Adds the assigned rows' terms (atomically: several GT rows may share a box).  Runs after
 // k_loss_grad_fill on the same stream.  One wavefront per GT row.
-__global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams p)
+__device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t block, float *s_val, int *s_idx)
 {
-    __shared__ float s_val[kPosThreads / 64];
-    __shared__ int s_idx[kPosThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = (int)(blockIdx.x / (uint32_t)p.pos_blocks);
-    const int blk = (int)blockIdx.x - b * p.pos_blocks;
+    const int b = (int)(block / (uint32_t)p.pos_blocks);
+    const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
     const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
     const int g = blk * kLossPosGtPerBlock + wave;
@@ -573,6 +618,24 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams 
     }
 }
 
+__global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams p)
+{
+    __shared__ float s_val[kPosThreads / 64];
+    __shared__ int s_idx[kPosThreads / 64];
+    loss_grad_pos(p, blockIdx.x, s_val, s_idx);
+}
+
+// After the fused forward + gradient-fill pass: the assigned rows' terms, and in one more
+// workgroup of the same launch the finalize step (the two are independent of each other).
+__global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos_finalize(const LossParams p)
+{
+    __shared__ float s_val[kPosThreads / 64];
+    __shared__ int s_idx[kPosThreads / 64];
+    __shared__ double s_sum[kPosThreads / kFinalizeLanes];
+    if (blockIdx.x + 1u == gridDim.x) loss_finalize<kPosThreads>(p, s_sum);
+    else loss_grad_pos(p, blockIdx.x, s_val, s_idx);
+}
+
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;
@@ -594,11 +657,20 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
     const size_t lds = (size_t)((p.pad + 1) / 2) * kPairStride * sizeof(float) + (size_t)p.pad * 5 * sizeof(float) +
                        (size_t)occ_words * sizeof(uint32_t);
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
-    if (p.iou_max) hipLaunchKernelGGL(k_loss_main<true>, grid, dim3(kLossNegThreads), lds, stm, p);
-    else hipLaunchKernelGGL(k_loss_main<false>, grid, dim3(kLossNegThreads), lds, stm, p);
+    const bool grad = p.grad_w != nullptr;                     // forward and gradient in one pass over the rows
+    if (p.iou_max) {
+        if (grad) hipLaunchKernelGGL((k_loss_main<true, true>), grid, dim3(kLossNegThreads), lds, stm, p);
+        else hipLaunchKernelGGL((k_loss_main<true, false>), grid, dim3(kLossNegThreads), lds, stm, p);
+    } else {
+        if (grad) hipLaunchKernelGGL((k_loss_main<false, true>), grid, dim3(kLossNegThreads), lds, stm, p);
+        else hipLaunchKernelGGL((k_loss_main<false, false>), grid, dim3(kLossNegThreads), lds, stm, p);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kFinalizeThreads), 0, stm, p);
+    if (grad)
+        hipLaunchKernelGGL(k_loss_grad_pos_finalize, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks + 1u), dim3(kPosThreads), 0, stm, p);
+    else
+        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kFinalizeThreads), 0, stm, p);
     return hipGetLastError();
 }
 

@@ -96,6 +96,7 @@ class DetectionHead:
         self.gt_rate = [float(r) for r in gt_rate]
         self._ws = {}
         self._configs = {}
+        self._grad_weights = {}
         self._plans = {}
         self._grown = {}
 
@@ -280,7 +281,7 @@ class DetectionHead:
     # --------------------------------------------------------------- loss
     def loss(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
              ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False,
-             out=None):
+             out=None, grad_per_image=None):
         """Per-image training loss (YOLOv3.py:117-310 / YOLOv2.py:105-173).
         ground_truth: [B, pad, 5] float32 CUDA tensor, -1 padded.
         Returns dict(per_image [B], sum [1], mean [1] (sum / B), parts [B,4] | None, iou_max [B,N] | None,
@@ -288,11 +289,15 @@ class DetectionHead:
         graph is recorded here: loss_with_grad does that.  out: the dict of an
         earlier call with the same shapes and options, whose tensors are then
         written again instead of new ones being allocated (a tight loop saves the
-        allocations' host time)."""
+        allocations' host time).  grad_per_image [B]: the gradient
+        d(sum_b grad_per_image[b] * loss_b) / d(head) is computed in the same pass
+        (yh_loss_with_grad) and returned under 'grads'; no noobj_mask then."""
         lib = _abi.load()
         heads = self._check_heads(heads)
         cfg = self.config_for(heads)
         dev = heads[0].device
+        if grad_per_image is not None and want_mask:
+            raise ValueError('the fused gradient pass records no noobj_mask')
         if ground_truth.device != dev:
             raise RuntimeError('ground_truth must live on the heads\' device')
         gt = ground_truth.to(torch.float32).contiguous()
@@ -318,16 +323,28 @@ class DetectionHead:
             iou = torch.empty((B, N), dtype=torch.float32, device=dev) if want_iou_max else None
             mask = torch.empty((B, N), dtype=torch.uint8, device=dev) if want_mask else None
         scales = (ctypes.c_float * 4)(float(coord_scale), float(noobj_scale), float(obj_scale), float(class_scale))
-        with torch.cuda.device(dev):
-            _abi.check(lib.yh_loss_forward(ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
-                                           gt.data_ptr(), B, pad, scales, float(ignore_threshold),
-                                           1 if normalize_by_num_gt else 0, ws.data_ptr(), ws.numel(),
-                                           per.data_ptr(), parts.data_ptr() if want_parts else None,
-                                           iou.data_ptr() if want_iou_max else None, total.data_ptr(),
-                                           mask.data_ptr() if want_mask else None, self._stream(dev)))
+        common = [ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]),
+                  gt.data_ptr(), B, pad, scales, float(ignore_threshold),
+                  1 if normalize_by_num_gt else 0, ws.data_ptr(), ws.numel(),
+                  per.data_ptr(), parts.data_ptr() if want_parts else None,
+                  iou.data_ptr() if want_iou_max else None, total.data_ptr()]
+        grads = None
+        if grad_per_image is not None:
+            gw = grad_per_image.to(torch.float32).contiguous()
+            if gw.shape != (B,) or gw.device != dev:
+                raise ValueError('grad_per_image must be [B] on the heads\' device')
+            grads = [torch.empty_like(h) for h in heads]
+            with torch.cuda.device(dev):
+                _abi.check(lib.yh_loss_with_grad(*common, gw.data_ptr(),
+                                                 _abi.pointer_array([g.data_ptr() for g in grads]), self._stream(dev)))
+        else:
+            with torch.cuda.device(dev):
+                _abi.check(lib.yh_loss_forward(*common, mask.data_ptr() if want_mask else None, self._stream(dev)))
         if out is not None:
+            out['grads'] = grads
             return out
-        return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask, _total=total)
+        return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask,
+                    _total=total, grads=grads)
 
     def loss_backward(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                       normalize_by_num_gt, noobj_mask, grad_per_image):
@@ -354,23 +371,20 @@ class DetectionHead:
 
     def loss_and_grad(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                       ignore_threshold, normalize_by_num_gt, grad_scale=1.0):
-        """Forward and backward in two library calls, without an autograd graph:
-        (loss() result, [d(grad_scale * sum of the per-image losses) / d(head)]).
-        For training loops that hand the gradients on themselves
-        (torch.autograd.backward(heads, grads)) and do not want the autograd
-        engine's thread hand-over between the two kernels."""
-        out = self.loss(heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
-                        ignore_threshold, normalize_by_num_gt, want_mask=True)
+        """Forward and backward in one library call (yh_loss_with_grad), without an
+        autograd graph: (loss() result, [d(grad_scale * sum of the per-image
+        losses) / d(head)]).  For training loops that hand the gradients on
+        themselves (torch.autograd.backward(heads, grads)): the upstream gradient
+        of reduce_mean is a constant known before the forward pass, so the
+        gradient tensor is filled while the ignore mask is computed."""
         B, dev = heads[0].shape[0], heads[0].device
         key = (B, float(grad_scale), dev)
-        gw = self._grad_weights.get(key) if hasattr(self, '_grad_weights') else None
+        gw = self._grad_weights.get(key)
         if gw is None:
-            if not hasattr(self, '_grad_weights'):
-                self._grad_weights = {}
             gw = self._grad_weights[key] = torch.full((B,), float(grad_scale), dtype=torch.float32, device=dev)
-        grads = self.loss_backward(heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
-                                   normalize_by_num_gt, out['noobj_mask'], gw)
-        return out, grads
+        out = self.loss(heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
+                        ignore_threshold, normalize_by_num_gt, grad_per_image=gw)
+        return out, out['grads']
 
     def loss_with_grad(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                        ignore_threshold, normalize_by_num_gt):

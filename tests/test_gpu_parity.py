@@ -479,8 +479,8 @@ def test_loss_backward_matches_oracle(gpu, version, B, G):
 
 
 def test_loss_and_grad_equals_the_autograd_path(gpu):
-    """Forward + backward as two library calls give the bits torch.autograd gets from
-    loss_with_grad for the same upstream factor."""
+    """loss_and_grad (the fused library call) gives the bits torch.autograd gets from
+    loss_with_grad (forward, then backward) for the same upstream factor."""
     case = cases.v3(size=96)
     B = 3
     heads = to_dev(case.heads(91, B, obj_mean=-1.0), gpu)

@@ -224,7 +224,7 @@ __device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, i
     const int d1 = s_ctl[0], cum1 = s_ctl[1], below = s_ctl[2];
     int d2 = 255, n = cum1;
     __syncthreads();
-    if (cum1 > kSelMax) {                                   // the boundary bin is too full: split it by the next byte
+    if (cum1 > target + (target >> 2)) {                    // the boundary bin overshoots: split it by the next byte
         s_hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < cnt; i += kSegThreads) {
@@ -252,6 +252,79 @@ __device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, i
     return n;
 }
 
+// wave_nms's walk by the four wavefronts of a workgroup (all kSegThreads threads call it; the
+// result is the same in every thread).  Every wavefront holds the tile's 64 candidates in its
+// registers; the tests against the boxes selected so far and the 64 x 64 tests inside the tile
+// are split four ways (a quarter of the selected list, sixteen columns of the bit matrix per
+// wavefront) and meet in LDS; wavefront 0 resolves the tile on the scalar unit and appends the
+// survivors.  Same decisions in the same order as wave_nms.
+struct BlockNmsLds {
+    unsigned long long dead[kSegThreads / 64];
+    uint16_t m16[64 * (kSegThreads / 64)];
+    int kept;
+};
+
+__device__ inline int block_nms(const unsigned long long *keys, int cnt, const float4 *boxes4, float (*kbox)[5],
+                                float thr, int max_boxes, int32_t *krow, float *kscore, BlockNmsLds &l)
+{
+    static_assert(kSegThreads == 256, "sixteen columns of the bit matrix per wavefront");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int kept = 0;
+    for (int t = 0; t < cnt && kept < max_boxes; t += 64) {
+        const int i = t + lane;
+        const bool valid = i < cnt;
+        const unsigned long long key = valid ? keys[i] : 0ull;
+        const int n = key_row(key);
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) bx = boxes4[n];
+        const float ymin = fminf(bx.x, bx.z), xmin = fminf(bx.y, bx.w);
+        const float ymax = fmaxf(bx.x, bx.z), xmax = fmaxf(bx.y, bx.w);
+        const float area = (ymax - ymin) * (xmax - xmin);
+        // against the boxes selected by earlier tiles: this wavefront's share of the list
+        bool alive = valid;
+        for (int j = kept - 1 - wave; j >= 0; j -= kSegThreads / 64) {
+            if (__ballot(alive) == 0ull) break;
+            const float *kb = kbox[j];
+            if (alive && suppresses(ymin, xmin, ymax, xmax, area, kb[0], kb[1], kb[2], kb[3], kb[4], thr))
+                alive = false;
+        }
+        const unsigned long long dead = __ballot(valid && !alive);
+        if (lane == 0) l.dead[wave] = dead;
+        __syncthreads();
+        unsigned long long alive_mask = __ballot(valid);
+#pragma unroll
+        for (int w = 0; w < kSegThreads / 64; ++w) alive_mask &= ~l.dead[w];
+        alive = (alive_mask >> lane) & 1ull;
+        // inside the tile: bit j of the mask = "the earlier lane j would suppress me"; columns 16 * wave ..
+        uint32_t m = 0u;
+        for (unsigned long long rem = alive_mask & (0xFFFFull << (16 * wave)); rem != 0ull; rem &= rem - 1ull) {
+            const int j = __ffsll((long long)rem) - 1;
+            const float jy0 = lane_bcast(ymin, j), jx0 = lane_bcast(xmin, j);
+            const float jy1 = lane_bcast(ymax, j), jx1 = lane_bcast(xmax, j);
+            const float ja = lane_bcast(area, j);
+            if (alive && lane > j && suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, ja, thr))
+                m |= 1u << (j - 16 * wave);
+        }
+        l.m16[lane * (kSegThreads / 64) + wave] = (uint16_t)m;
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long mymask = *reinterpret_cast<const unsigned long long *>(&l.m16[lane * (kSegThreads / 64)]);
+            const unsigned long long keepmask = resolve_tile(alive_mask, mymask, max_boxes - kept);
+            if ((keepmask >> lane) & 1ull) {
+                const int pos = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
+                kbox[pos][0] = ymin; kbox[pos][1] = xmin; kbox[pos][2] = ymax; kbox[pos][3] = xmax;
+                kbox[pos][4] = area;
+                krow[pos] = n;
+                kscore[pos] = key_score(key);
+            }
+            if (lane == 0) l.kept = kept + __popcll(keepmask);
+        }
+        __syncthreads();
+        kept = l.kept;
+    }
+    return kept;
+}
+
 __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
 {
     __shared__ unsigned long long s_keys[kSortLds];
@@ -260,6 +333,7 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     float (*s_kbox)[5] = reinterpret_cast<float (*)[5]>(s_dyn);
     __shared__ int s_hist[kSegThreads];
     __shared__ int s_ctl[4];
+    __shared__ BlockNmsLds s_walk;
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int b = seg / p.C;
     const int cnt = p.seg_cnt[seg];
@@ -278,6 +352,11 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         return wave_nms<false>(sorted, n, boxes4, nullptr, s_kbox, p.iou_thr, p.max_boxes,
                                p.kept_row + (long long)seg * p.max_boxes,
                                p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
+    };
+    auto block_walk = [&](const unsigned long long *sorted, int n) {    // the whole workgroup
+        return block_nms(sorted, n, boxes4, s_kbox, p.iou_thr, p.max_boxes,
+                         p.kept_row + (long long)seg * p.max_boxes,
+                         p.kept_score + (long long)seg * p.max_boxes, s_walk);
     };
 
     if (cnt <= 64) {
@@ -303,31 +382,25 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     if (cnt <= kSortLds) {
         for (int i = tid; i < cnt; i += kSegThreads) s_keys[i] = keys[i];
         __syncthreads();
-        const int target = 2 * p.max_boxes > 256 ? 2 * p.max_boxes : 256;
+        // a prefix of about 240 keys sorts as 256 (the selection overshoots its target by a few keys)
+        const int target = 2 * p.max_boxes > 240 ? 2 * p.max_boxes : 240;
         if (cnt >= 2 * target && target <= kSelMax) {
             const int n = select_prefix(s_keys, cnt, target, s_sel, s_hist, s_ctl);
             if (n > 0) {
                 int n2 = 128;
                 while (n2 < n) n2 <<= 1;
                 bitonic_sort<kSegThreads>(s_sel, n, n2);
-                if (tid < 64) {
-                    const int kept = walk(s_sel, n);
-                    if (tid == 0) {
-                        const bool done = kept >= p.max_boxes || n == cnt;
-                        s_ctl[0] = done ? 1 : 0;
-                        if (done) p.kept_cnt[seg] = kept;
-                    }
+                const int kept = block_walk(s_sel, n);
+                if (kept >= p.max_boxes || n == cnt) {
+                    if (tid == 0) p.kept_cnt[seg] = kept;
+                    return;
                 }
-                __syncthreads();
-                if (s_ctl[0]) return;
-                __syncthreads();
             }
         }
         int n2 = 128;
         while (n2 < cnt) n2 <<= 1;
         bitonic_sort<kSegThreads>(s_keys, cnt, n2);
-        if (tid >= 64) return;
-        const int kept = walk(s_keys, cnt);
+        const int kept = block_walk(s_keys, cnt);
         if (tid == 0) p.kept_cnt[seg] = kept;
         return;
     }
@@ -335,9 +408,8 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     while (n2 < cnt) n2 <<= 1;
     __syncthreads();
     bitonic_sort<kSegThreads>(keys, cnt, n2);
-    __syncthreads();          // sorted keys in global memory, visible to wave 0
-    if (tid >= 64) return;
-    const int kept = walk(keys, cnt);
+    __syncthreads();          // sorted keys in global memory, visible to the whole workgroup
+    const int kept = block_walk(keys, cnt);
     if (tid == 0) p.kept_cnt[seg] = kept;
 }
 

@@ -157,17 +157,53 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
 
 // NonMaxSuppressionV3's overlap test on corner-normalised boxes with
 // precomputed areas: non-positive area never suppresses, the intersection is
-// clamped at zero, the comparison is strict.
+// clamped at zero, the comparison is strict: RN(inter / union) > thr.
+// The division is the costly part of the test and almost never needed: with
+// d = inter - thr * union (one rounding) and the margin m = 2^-20 * union + 2^-100
+// (thr lies in [0, 1]), d > m implies RN(inter / union) > thr and d < -m the
+// opposite, because the roundings involved stay below 2^-22 relative; only a pair
+// inside the margin, or with a union that is not positive, takes the division.
+// Same decision in every case.
 __device__ __forceinline__ bool suppresses(float ymin_i, float xmin_i, float ymax_i, float xmax_i, float area_i,
                                            float ymin_j, float xmin_j, float ymax_j, float xmax_j, float area_j,
                                            float thr)
 {
-    if (area_i <= 0.0f || area_j <= 0.0f) return false;
+    if (!(area_i > 0.0f && area_j > 0.0f)) return false;    // a NaN area ends in "false" either way
     const float iy = fmaxf(fminf(ymax_i, ymax_j) - fmaxf(ymin_i, ymin_j), 0.0f);
     const float ix = fmaxf(fminf(xmax_i, xmax_j) - fmaxf(xmin_i, xmin_j), 0.0f);
     const float inter = iy * ix;
-    const float iou = inter / ((area_i + area_j) - inter);
-    return iou > thr;
+    const float uni = (area_i + area_j) - inter;
+    const float d = __builtin_fmaf(-thr, uni, inter);
+    const float m = __builtin_fmaf(0x1p-20f, uni, 0x1p-100f);
+    if (uni > 0.0f && uni < 0x1p100f && inter < 0x1p100f) {   // finite, no overflow in d
+        if (d > m) return true;
+        if (d < -m) return false;
+    }
+    return inter / uni > thr;
+}
+
+// Greedy resolve of a tile in score order: a lane is selected iff no SELECTED earlier lane
+// suppresses it, until `room` lanes are selected.  alive: the tile's candidates that survived the
+// earlier tiles; mymask: this lane's bits "the earlier lane j would suppress me".  Lanes nobody
+// could suppress are selected whatever happens to the others, so only the lanes with a non-empty
+// mask are walked (on the scalar unit, in lane order); cutting the selection at `room` afterwards
+// is the same as stopping there, since a lane's fate depends on earlier lanes only.
+__device__ __forceinline__ unsigned long long resolve_tile(unsigned long long alive, unsigned long long mymask, int room)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long contested = __ballot(mymask != 0ull) & alive;
+    unsigned long long keepmask = alive & ~contested;
+    const int m_lo = (int)(uint32_t)mymask, m_hi = (int)(uint32_t)(mymask >> 32);
+    for (unsigned long long rem = contested; rem != 0ull; rem &= rem - 1ull) {
+        const int j = __ffsll((long long)rem) - 1;
+        const unsigned long long mj =
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_hi, j) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane(m_lo, j);
+        if ((mj & keepmask) == 0ull) keepmask |= 1ull << j;
+    }
+    // the first `room` selected lanes
+    const bool mine = ((keepmask >> lane) & 1ull) && __popcll(keepmask & ((1ull << lane) - 1ull)) < room;
+    return __ballot(mine);
 }
 
 // Greedy NMS of one sorted segment by ONE wavefront (all 64 lanes call it):
@@ -220,17 +256,7 @@ __device__ inline int wave_nms(const unsigned long long *keys, int cnt, const fl
             if (alive && lane > j && suppresses(ymin, xmin, ymax, xmax, area, jy0, jx0, jy1, jx1, ja, thr))
                 mymask |= 1ull << j;
         }
-        // greedy resolve in score order: a lane is selected iff no SELECTED earlier lane suppresses it
-        unsigned long long keepmask = 0ull;
-        int room = max_boxes - kept;
-        const int m_lo = (int)(uint32_t)mymask, m_hi = (int)(uint32_t)(mymask >> 32);
-        for (unsigned long long rem = alive_mask; rem != 0ull && room > 0; rem &= rem - 1ull) {
-            const int j = __ffsll((long long)rem) - 1;
-            const unsigned long long mj =
-                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(m_hi, j) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane(m_lo, j);
-            if ((mj & keepmask) == 0ull) { keepmask |= 1ull << j; --room; }
-        }
+        const unsigned long long keepmask = resolve_tile(alive_mask, mymask, max_boxes - kept);
         if ((keepmask >> lane) & 1ull) {
             const int pos = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
             kbox[pos][0] = ymin; kbox[pos][1] = xmin; kbox[pos][2] = ymax; kbox[pos][3] = xmax;

@@ -261,6 +261,7 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
     p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg);
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
     p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
+    p.scan_col_step = 1024 % p.K;
     uint32_t row_base = 0;
     for (int s = 0; s < p.S; ++s) {
         yh::StreamScale &sc = p.sc[s];
@@ -617,6 +618,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     p.S = 1; p.B = batch; p.C = num_classes; p.P = 1; p.K = num_classes; p.N = (int32_t)boxes_per_img;
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
     p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
+    p.scan_col_step = 1024 % p.K;
     p.thr = score_threshold;
     p.cand_cap = max_candidates;
     p.cand = w.cand;

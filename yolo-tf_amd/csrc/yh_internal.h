@@ -71,6 +71,7 @@ struct StreamParams {
     int32_t S, B, C, P, K, N;
     uint32_t magic_k;       // floor(2^32 / K) + 1
     uint32_t magic_c;       // floor(2^32 / C) + 1
+    int32_t scan_col_step;  // (floats a workgroup scans per step: 4 * 256) mod K
     int32_t tile_rows;      // rows per LDS tile: floor((tile floats - 3) / K)
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront

@@ -44,9 +44,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 struct Stage {
     float tile[kTileFloats];
     unsigned long long keys[kStage];
-    uint16_t rows[kTileFloats / 6 + 1];   // rows that passed step A (K >= 6)
-    uint16_t hits[kHitCap];               // (row, class) items that passed the prefilter (item < kTileFloats)
-    int nrows;
+    uint16_t hits[kHitCap];               // class logits that passed the prefilter: float index inside the tile
     int nhits;
     int count;
     int base;
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 {
     __shared__ __attribute__((aligned(16))) Stage st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { st.count = 0; st.nrows = 0; st.nhits = 0; }
+    if (tid == 0) { st.count = 0; st.nhits = 0; }
 
     int s = 0;
 #pragma unroll
@@ -159,27 +157,17 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         __syncthreads();                                      // waits for the DMA (vmcnt) and publishes the tile
         const float *tile = st.tile + sh;
 
-        // ---- A: rows whose objectness can still reach the threshold
-        int nrows;
-        if (MODE == kModeDetect) {
-            for (int rr = tid; rr < rows_t; rr += kThreads) {
-                if (tile[rr * K + C + 4] >= pf) st.rows[atomicAdd(&st.nrows, 1)] = (uint16_t)rr;
-            }
-            __syncthreads();
-            nrows = st.nrows;
-        } else {
-            nrows = rows_t;
-        }
-        // ---- B: class logits of those rows, spread over all lanes, in two steps: the cheap
-        // prefilter collects the items that pass, then the lanes take the collected items
-        // densely.  (Doing the exact test where an item is found leaves one or two lanes of a
-        // wavefront working while the others wait: with dense candidates that made the kernel
-        // compute-bound at a few percent lane utilisation.)  An item that finds the list full
-        // is worked on where it was found.
-        const int items = nrows * C;
-        auto exact = [&](int item) {
-            const int ri = item / C, c = item - ri * C;
-            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
+        // ---- scan: every float of the window against the prefilter, 16 bytes per lane and step.
+        // A float is a class logit when its column (float index mod K) is below C; the column of
+        // a lane's first float is kept up to date by adding (4 * kThreads) mod K per step.  The
+        // rare hits (in detect mode: those whose row's objectness can still reach the threshold)
+        // are collected, then the lanes take the collected items densely.  (Doing the exact test
+        // where an item is found leaves one or two lanes of a wavefront working while the others
+        // wait: with dense candidates that made the kernel compute-bound at a few percent lane
+        // utilisation.)  An item that finds the list full is worked on where it was found.
+        const int valid = rows_t * K;
+        auto exact = [&](int fi) {
+            const int rr = (int)__umulhi((uint32_t)fi, p.magic_k), c = fi - rr * K;      // fi < 2^13
             const float *rp = tile + rr * K;
             const float x = rp[c];
             const uint32_t row = row_t + (uint32_t)rr;
@@ -195,20 +183,31 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
                 }
             }
         };
-        for (int item = tid; item < items; item += kThreads) {
-            const int ri = (int)__umulhi((uint32_t)item, p.magic_c), c = item - ri * C;   // item < 2^13
-            const int rr = (MODE == kModeDetect) ? (int)st.rows[ri] : ri;
-            if (tile[rr * K + c] >= pf) {
-                const int slot = atomicAdd(&st.nhits, 1);
-                if (slot < kHitCap) st.hits[slot] = (uint16_t)item;
-                else exact(item);
+        int fi0 = 4 * tid - sh;                               // tile index of this lane's first float; -3 .. -1: before the tile
+        int col0 = fi0 >= 0 ? fi0 - (int)__umulhi((uint32_t)fi0, p.magic_k) * K : fi0 + K;
+        for (int w = tid; w < wslots; w += kThreads, fi0 += 4 * kThreads) {
+            const float4 v = reinterpret_cast<const float4 *>(st.tile)[w];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = col0 + k;
+                c = c >= K ? c - K : c;
+                const int fi = fi0 + k;
+                if (vv[k] >= pf && c < C && (uint32_t)fi < (uint32_t)valid) {
+                    if (MODE == kModeDetect && !(tile[fi - c + C + 4] >= pf)) continue;   // the row's objectness rules it out
+                    const int slot = atomicAdd(&st.nhits, 1);
+                    if (slot < kHitCap) st.hits[slot] = (uint16_t)fi;
+                    else exact(fi);
+                }
             }
+            col0 += p.scan_col_step;
+            col0 = col0 >= K ? col0 - K : col0;
         }
         __syncthreads();
         const int nhits = st.nhits < kHitCap ? st.nhits : kHitCap;
         for (int h = tid; h < nhits; h += kThreads) exact(st.hits[h]);
         __syncthreads();
-        if (tid == 0) { st.nrows = 0; st.nhits = 0; }
+        if (tid == 0) st.nhits = 0;
         if (st.count >= kStage / 2) flush_candidates(st, p, b);
     }
     __syncthreads();

@@ -41,10 +41,11 @@ constexpr int kHitCap = 896;     // class logits that passed the prefilter, coll
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+static_assert(kTileFloats / 4 <= 4096, "a scan entry keeps the slot number in 12 bits");
 struct Stage {
     float tile[kTileFloats];
     unsigned long long keys[kStage];
-    uint16_t hits[kHitCap];               // class logits that passed the prefilter: float index inside the tile
+    uint16_t hits[kHitCap];               // scan entries: 16-byte slot of the window (12 bits) | a bit per float that passed
     int nhits;
     int count;
     int base;
@@ -158,22 +159,27 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         const float *tile = st.tile + sh;
 
         // ---- scan: every float of the window against the prefilter, 16 bytes per lane and step.
-        // A float is a class logit when its column (float index mod K) is below C; the column of
-        // a lane's first float is kept up to date by adding (4 * kThreads) mod K per step.  The
-        // rare hits (in detect mode: those whose row's objectness can still reach the threshold)
-        // are collected, then the lanes take the collected items densely.  (Doing the exact test
-        // where an item is found leaves one or two lanes of a wavefront working while the others
-        // wait: with dense candidates that made the kernel compute-bound at a few percent lane
-        // utilisation.)  An item that finds the list full is worked on where it was found.
+        // The scan is conservative and cheap: a float passes when it reaches the prefilter and its
+        // column (float index mod K; the column of a lane's first float is kept up to date by
+        // adding (4 * kThreads) mod K per step) is not one of the K - C columns behind the class
+        // logits.  A lane with a hit leaves ONE entry (slot number and a bit per float) in the
+        // list; the lanes then take the entries densely and the exact step sorts out what the
+        // scan let through (floats outside the tile, columns that wrapped into the next row).
+        // (Doing the exact test where an item is found leaves one or two lanes of a wavefront
+        // working while the others wait: with dense candidates that made the kernel
+        // compute-bound at a few percent lane utilisation.)  An entry that finds the list full
+        // is worked on where it was found.
         const int valid = rows_t * K;
         auto exact = [&](int fi) {
+            if ((uint32_t)fi >= (uint32_t)valid) return;      // the window's few floats around the tile
             const int rr = (int)__umulhi((uint32_t)fi, p.magic_k), c = fi - rr * K;      // fi < 2^13
+            if (c >= C) return;
             const float *rp = tile + rr * K;
             const float x = rp[c];
             const uint32_t row = row_t + (uint32_t)rr;
             const int n = (int)(sc.row_base + row);
             if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
-                push_candidate(st, p, b, make_key(c, x, n));
+                if (x >= pf) push_candidate(st, p, b, make_key(c, x, n));
             } else {
                 const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
                 if (cf >= p.thr) {
@@ -183,29 +189,37 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
                 }
             }
         };
-        int fi0 = 4 * tid - sh;                               // tile index of this lane's first float; -3 .. -1: before the tile
-        int col0 = fi0 >= 0 ? fi0 - (int)__umulhi((uint32_t)fi0, p.magic_k) * K : fi0 + K;
-        for (int w = tid; w < wslots; w += kThreads, fi0 += 4 * kThreads) {
+        auto exact_bits = [&](int w, uint32_t bits) {        // the set floats of slot w
+            while (bits) {
+                const int k = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                exact(4 * w + k - sh);
+            }
+        };
+        const uint32_t behind = (uint32_t)(K - C);            // columns C .. K-1 hold no class logit
+        const int fi_first = 4 * tid - sh;                    // -3 .. -1: before the tile
+        int col0 = fi_first >= 0 ? fi_first - (int)__umulhi((uint32_t)fi_first, p.magic_k) * K : fi_first + K;
+        for (int w = tid; w < wslots; w += kThreads) {
             const float4 v = reinterpret_cast<const float4 *>(st.tile)[w];
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int c = col0 + k;
-                c = c >= K ? c - K : c;
-                const int fi = fi0 + k;
-                if (vv[k] >= pf && c < C && (uint32_t)fi < (uint32_t)valid) {
-                    if (MODE == kModeDetect && !(tile[fi - c + C + 4] >= pf)) continue;   // the row's objectness rules it out
-                    const int slot = atomicAdd(&st.nhits, 1);
-                    if (slot < kHitCap) st.hits[slot] = (uint16_t)fi;
-                    else exact(fi);
-                }
+            const uint32_t t0 = (uint32_t)(col0 - C);
+            uint32_t hit = (v.x >= pf && t0 >= behind) ? 1u : 0u;
+            hit |= (v.y >= pf && t0 + 1u >= behind) ? 2u : 0u;
+            hit |= (v.z >= pf && t0 + 2u >= behind) ? 4u : 0u;
+            hit |= (v.w >= pf && t0 + 3u >= behind) ? 8u : 0u;
+            if (hit) {
+                const int slot = atomicAdd(&st.nhits, 1);
+                if (slot < kHitCap) st.hits[slot] = (uint16_t)((uint32_t)w | (hit << 12));
+                else exact_bits(w, hit);
             }
             col0 += p.scan_col_step;
             col0 = col0 >= K ? col0 - K : col0;
         }
         __syncthreads();
         const int nhits = st.nhits < kHitCap ? st.nhits : kHitCap;
-        for (int h = tid; h < nhits; h += kThreads) exact(st.hits[h]);
+        for (int h = tid; h < nhits; h += kThreads) {
+            const uint32_t e = st.hits[h];
+            exact_bits((int)(e & 0xFFFu), e >> 12);
+        }
         __syncthreads();
         if (tid == 0) st.nhits = 0;
         if (st.count >= kStage / 2) flush_candidates(st, p, b);

@@ -377,6 +377,36 @@ def test_long_segment_sorts_in_global_memory(gpu, c_oracle):
     assert (conf.cpu().numpy() >= 0.01).sum(axis=1).max() > 2048
 
 
+@pytest.mark.parametrize('N,C,clusters,mb,iou', [
+    (1500, 2, 6, 20, 0.5),      # ~750 per class around 6 objects: every tile is contested, the sorted prefix runs out
+    (6000, 3, 40, 100, 0.3),    # ~2000 per class: LDS-sized segments, selection beyond the first tile
+    (9000, 2, 15, 200, 0.4),    # > 2048 per class: segments sorted in global memory
+    (300, 4, 5, 60, 0.3),       # short segments: single-launch stage
+])
+def test_nms_of_clustered_boxes(gpu, c_oracle, N, C, clusters, mb, iou):
+    """Boxes jittered around a few objects, as a detector's candidates are: most candidates are
+    suppressed, tiles of the walk are full of mutual overlaps, and max_boxes is often not reached
+    inside the sorted prefix.  Selections bit-identical to the oracle's greedy walk."""
+    rng = np.random.default_rng(N + C)
+    B = 2
+    centre = rng.uniform(60, 340, size=(B, clusters, 2)).astype(np.float32)
+    size = rng.uniform(30, 120, size=(B, clusters, 2)).astype(np.float32)
+    which = rng.integers(0, clusters, size=(B, N))
+    c = np.take_along_axis(centre, which[..., None], axis=1) + rng.normal(0, 6, size=(B, N, 2)).astype(np.float32)
+    s = np.take_along_axis(size, which[..., None], axis=1) * rng.uniform(0.8, 1.25, size=(B, N, 2)).astype(np.float32)
+    boxes = np.concatenate([c - s / 2, c + s / 2], axis=-1).astype(np.float32)
+    conf = rng.uniform(0.0, 1.0, size=(B, N, C)).astype(np.float32)
+    conf[rng.uniform(size=conf.shape) < 0.5 / C] = 0.0         # some pairs below any threshold
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    got = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), 0.05, iou, mb).per_image()
+    want = c_oracle.nms(boxes, conf, 0.05, iou, mb)
+    cases.same_detections(got, want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0].view(np.uint32), w[0].view(np.uint32))
+        assert np.array_equal(g[3], w[3])
+    assert 0 < sum(len(g[0]) for g in got) < B * C * mb       # suppression, not max_boxes, ended most walks
+
+
 def test_tied_scores_take_lower_row_first(gpu, c_oracle):
     rng = np.random.default_rng(3)
     B, N, C = 2, 300, 4

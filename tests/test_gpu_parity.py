@@ -407,6 +407,33 @@ def test_nms_of_clustered_boxes(gpu, c_oracle, N, C, clusters, mb, iou):
     assert 0 < sum(len(g[0]) for g in got) < B * C * mb       # suppression, not max_boxes, ended most walks
 
 
+@pytest.mark.parametrize('iou', [0.5, 0.3, 0.7])
+def test_overlaps_at_the_iou_threshold(gpu, c_oracle, iou):
+    """Pairs whose IoU sits on the threshold or a few ulps around it: the overlap test decides most
+    pairs without the division, these take it; the comparison is strict (an IoU equal to the
+    threshold does not suppress).  One pair per class; selections as the oracle's."""
+    C = 96
+    rng = np.random.default_rng(17)
+    boxes = np.zeros((1, 2 * C, 4), np.float32)
+    conf = np.zeros((1, 2 * C, C), np.float32)
+    t = np.float32(iou)
+    for c in range(C):
+        h, w = np.float32(rng.uniform(3, 300)), np.float32(rng.uniform(3, 300))
+        y0, x0 = np.float32(rng.uniform(0, 50)), np.float32(rng.uniform(0, 50))
+        frac = t                                       # B inside A, IoU = area(B) / area(A) ~ frac
+        for _ in range(c % 9):                         # 0..8 ulps above, then below, the threshold
+            frac = np.nextafter(frac, np.float32(2.0 if (c // 9) % 2 == 0 else 0.0), dtype=np.float32)
+        boxes[0, 2 * c] = (y0, x0, y0 + h, x0 + w)
+        boxes[0, 2 * c + 1] = (y0, x0, y0 + h, x0 + w * frac)
+        conf[0, 2 * c, c], conf[0, 2 * c + 1, c] = 0.9, 0.8
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    got = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), 0.5, iou, 10).per_image()
+    want = c_oracle.nms(boxes, conf, 0.5, iou, 10)
+    cases.same_detections(got, want)
+    kept = len(got[0][0])
+    assert C < kept < 2 * C                            # some second boxes suppressed, some not
+
+
 def test_tied_scores_take_lower_row_first(gpu, c_oracle):
     rng = np.random.default_rng(3)
     B, N, C = 2, 300, 4

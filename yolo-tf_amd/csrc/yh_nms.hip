@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(const NmsParams p)
 // twice with every thread contending for the C counters in LDS.  For candidates that live in
 // the list only (no private slots, no slot-indexed boxes).  class_hist, class_cursor and
 // img_count are zero between calls: k_sort_nms clears them.
-constexpr int kBinSlice = 8192;
+constexpr int kBinSlice = 2048;
 constexpr int kBinSliceThreads = 256;
 
 __device__ __forceinline__ void slice_range(const NmsParams &p, int b, int sub, int &begin, int &end, int &raw)

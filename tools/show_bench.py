@@ -2,7 +2,8 @@
 """One-line digest of bench.py JSON files."""
 import json, sys
 for path in sys.argv[1:]:
-    d = json.load(open(path))
+    # the JSON line is the last line that starts with a brace (a gloo rehearsal prints its own lines first)
+    d = json.loads([line for line in open(path) if line.startswith('{')][-1])
     r = d.get('roofline') or {}
     c = d['config']
     print('%s: %.0f %s  %.2f us/step  kernel %.2f us frac %s  in_flight %s serial %s enqueue %s' % (

@@ -45,6 +45,28 @@ def test_decode_matches_oracle(gpu, c_oracle, case_fn, B):
     assert_close(conf[0].cpu().numpy(), nc, rtol=RTOL, atol=1e-30, what='conf vs numpy')
 
 
+@pytest.mark.parametrize('grid,P', [((7, 1), 1), ((1, 9), 1), ((1, 1), 3), ((5, 4), 1), ((3, 1), 5)])
+def test_decode_and_detect_on_degenerate_grids(gpu, grid, P):
+    """One prior, one column, one cell: the row -> (cell, prior) -> (y, x) arithmetic of the
+    kernels has no division, so its divisors of 1 are cases of their own."""
+    C = 4
+    rng = np.random.default_rng(5)
+    priors = [rng.uniform(0.5, 3.0, size=(P, 2)).astype(np.float32)]
+    heads = y.synth.make_heads(15, 2, [grid], P, C, obj_mean=1.0)
+    hd = y.DetectionHead(C, priors, (32.0,), (32.0,))
+    boxes, conf = hd.decode(to_dev(heads, gpu))
+    for b in range(2):
+        nb, nc = O.decode([h[b] for h in heads], priors, (32.0,), C)
+        assert_close(boxes[b].cpu().numpy(), nb, rtol=RTOL, atol=RTOL * 32 * max(grid), what='boxes')
+        assert_close(conf[b].cpu().numpy(), nc, rtol=RTOL, atol=1e-30, what='conf')
+    got = hd.detect(to_dev(heads, gpu), 0.3, 0.5, 10)
+    staged = hd.nms(boxes, conf, 0.3, 0.5, 10)
+    cases.same_detections(got.per_image(), staged.per_image())
+    for g, s in zip(got.per_image(), staged.per_image()):
+        assert np.array_equal(g[1], s[1])                      # the fused path's boxes are the decode kernel's
+    assert int(got.count.sum()) > 0
+
+
 def test_decode_without_conf(gpu, c_oracle):
     case = cases.v2()
     heads = case.heads(12, 2)

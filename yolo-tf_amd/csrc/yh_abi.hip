@@ -269,6 +269,10 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
         sc.rows_img = (uint32_t)cfg->grid_h[s] * cfg->grid_w[s] * cfg->num_priors;
         sc.span = sc.rows_img * (uint32_t)p.K;
         sc.grid_w = (uint32_t)cfg->grid_w[s];
+        // floor(2^32 / d), capped for d = 1: the kernels' quotient estimate stays at most one too small
+        auto recip = [](uint64_t d) { const uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
+        sc.magic_w = recip(sc.grid_w);
+        sc.magic_p = recip((uint64_t)cfg->num_priors);
         sc.row_base = row_base;
         sc.mult = cfg->box_mult[s];
         std::memcpy(sc.prior_hw, cfg->prior_hw[s], sizeof(sc.prior_hw));
@@ -627,6 +631,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     p.sc[0].rows_img = (uint32_t)boxes_per_img;
     p.sc[0].span = (uint32_t)(boxes_per_img * num_classes);
     p.sc[0].grid_w = 1;
+    p.sc[0].magic_w = 0xFFFFFFFFu; p.sc[0].magic_p = 0xFFFFFFFFu;
     const yh::NmsParams q = make_nms_params(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold,
                                             nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
                                             out_class, out_index, out_class_candidates, status);

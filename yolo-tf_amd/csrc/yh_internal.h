@@ -58,6 +58,8 @@ struct StreamScale {
     uint32_t rows_img;      // rows of one image at this scale
     uint32_t span;          // rows_img * K floats
     uint32_t grid_w;
+    uint32_t magic_w;       // floor(2^32 / grid_w): quotient estimate, at most one too small
+    uint32_t magic_p;       // floor(2^32 / P)
     uint32_t row_base;      // first box row of this scale inside an image
     uint32_t blk_begin;     // first workgroup of this scale in the launch
     uint32_t unit_base;     // wave-private variant: first work unit of this scale inside an image

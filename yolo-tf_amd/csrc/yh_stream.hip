@@ -68,10 +68,14 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
 __device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float ty, float tx, float th,
                                              float tw, uint32_t row)
 {
-    const uint32_t cell = row / (uint32_t)P;
-    const uint32_t pi = row - cell * (uint32_t)P;
-    const uint32_t gy = cell / sc.grid_w;
-    const uint32_t gx = cell - gy * sc.grid_w;
+    // row = (gy * grid_w + gx) * P + pi, taken apart without integer division: the product with
+    // floor(2^32 / d) gives the quotient or one less, one comparison settles it
+    uint32_t cell = __umulhi(row, sc.magic_p);
+    uint32_t pi = row - cell * (uint32_t)P;
+    if (pi >= (uint32_t)P) { pi -= (uint32_t)P; ++cell; }
+    uint32_t gy = __umulhi(cell, sc.magic_w);
+    uint32_t gx = cell - gy * sc.grid_w;
+    if (gx >= sc.grid_w) { gx -= sc.grid_w; ++gy; }
     const float by = ((float)gy + 0.5f) + sigmoidf(ty);
     const float bx = ((float)gx + 0.5f) + sigmoidf(tx);
     const float bh = sc.prior_hw[pi][0] + expf(th);

@@ -9,16 +9,15 @@
 // once; the 16-byte phase of the tile start is absorbed by an aligned window
 // plus a dword shift inside LDS.
 //
-// The tile is then consumed row-wise from LDS (row pitch K dwords; lanes on
-// consecutive rows or consecutive channels hit distinct banks):
-//   A. one lane per row reads the objectness logit; since
-//      conf = sigmoid(x) * sigmoid(obj) <= min(sigmoid(x), sigmoid(obj)),
-//      a row whose objectness is below a conservatively lowered logit(thr)
-//      cannot yield a candidate and is dropped with a single compare;
-//   B. the surviving rows' class logits are spread over all lanes: one pass
-//      collects the items that pass the same prefilter, a second, dense pass
-//      gives them the exact sigmoid product and threshold, and real candidates
-//      decode their box from the tile and stage a key.
+// The tile is then consumed from LDS in two steps:
+//   A. a flat scan, 16 bytes per lane and step, tests every float against a
+//      conservatively lowered logit(thr) (conf = sigmoid(x) * sigmoid(obj) <=
+//      min(sigmoid(x), sigmoid(obj)), so a class logit below it cannot yield a
+//      candidate) and a cheap "is a class column" rule, and leaves one entry per
+//      lane with a hit in an LDS list;
+//   B. a dense pass over the entries gives them the exact column check, the
+//      exact sigmoid product and threshold, and real candidates decode their
+//      box from the tile and stage a key.
 // The [N][C] confidence matrix is never materialised and nothing is read
 // twice from memory.  One global atomic per flush of the staged keys reserves
 // the range in the image's candidate list; the launch is oversubscribed (a few

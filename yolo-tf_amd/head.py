@@ -428,7 +428,9 @@ class DetectPipeline:
     sets alternate: a returned Detections object stays valid until the
     second submit after it.  Results per batch are those of detect(); a batch
     whose candidate capacity overflowed is flagged (Detections.overflowed) and
-    has to be submitted again to a pipeline with a larger max_candidates."""
+    has to be submitted again to a pipeline with a larger max_candidates.
+    Thresholds, max_boxes and the stream are fixed at construction: the call of
+    a slot is prepared once and reused while batches keep their shape."""
 
     def __init__(self, head, score_threshold, iou_threshold, max_boxes, max_candidates=None,
                  want_class_candidates=False, stream=None, tag=0):

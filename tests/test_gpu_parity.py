@@ -811,3 +811,27 @@ def test_abi_rejects_bad_arguments(gpu):
     assert e.value.code in (y._abi.YH_ERR_LIMIT, y._abi.YH_ERR_INVALID_ARG)
     with pytest.raises(RuntimeError):
         hd.detect([h.cpu() for h in heads], 0.5, 0.5, 10)  # no CPU path
+    # the fused loss + gradient call: gradient tensors must exist and must not be the heads
+    import ctypes
+    lib = y._abi.load()
+    gt = torch.from_numpy(y.synth.make_ground_truth(172, 1, 2, 4, 416, case.C)).to(gpu)
+    cfg = hd.config_for(heads)
+    nbytes = ctypes.c_size_t(0)
+    y._abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), 1, 4, ctypes.byref(nbytes)))
+    ws = torch.zeros(max(nbytes.value, 256), dtype=torch.uint8, device=gpu)
+    per, total, gw = torch.empty(1, device=gpu), torch.empty(2, device=gpu), torch.ones(1, device=gpu)
+    scales = (ctypes.c_float * 4)(1., 1., 5., 1.)
+    hp = y._abi.pointer_array([h.data_ptr() for h in heads])
+    st = ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+
+    def call(gw_ptr, grads):
+        return lib.yh_loss_with_grad(ctypes.byref(cfg), hp, gt.data_ptr(), 1, 4, scales, 0.6, 0, ws.data_ptr(), ws.numel(),
+                                     per.data_ptr(), None, None, total.data_ptr(), gw_ptr, grads, st)
+    assert call(None, hp) == y._abi.YH_ERR_INVALID_ARG
+    assert call(gw.data_ptr(), None) == y._abi.YH_ERR_INVALID_ARG
+    assert call(gw.data_ptr(), hp) == y._abi.YH_ERR_INVALID_ARG            # gradient tensors alias the heads
+    assert call(gw.data_ptr(), y._abi.pointer_array([0])) == y._abi.YH_ERR_INVALID_ARG
+    good = [torch.empty_like(h) for h in heads]
+    assert call(gw.data_ptr(), y._abi.pointer_array([g.data_ptr() for g in good])) == y._abi.YH_OK
+    torch.cuda.synchronize()
+    assert torch.isfinite(per).all() and int((good[0] != 0).sum()) > 0

@@ -89,11 +89,14 @@ __device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float
 }
 
 // Appends the staged candidate keys to the image's list: one global atomic per
-// call reserves the range.  Called by every thread of the workgroup.
-__device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &p, int b)
+// call reserves the range.  Called by every thread of the workgroup with the
+// value st.count had after the last barrier (the caller reads it before it puts
+// the next tile's LDS-DMA loads in flight: an LDS read behind them would wait for
+// them, and the atomic below is meant to travel together with them).
+__device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &p, int b, int staged)
 {
     const int tid = threadIdx.x;
-    const int cnt = st.count < kStage ? st.count : kStage;   // same value in every thread (read after a barrier)
+    const int cnt = staged < kStage ? staged : kStage;
     if (cnt > 0) {
         if (tid == 0) st.base = atomicAdd(&p.img_count[b], cnt);
         __syncthreads();
@@ -135,14 +138,13 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     uint32_t row_end = row_begin + sc.tiles_per_chunk * (uint32_t)R;
     if (row_end > sc.rows_img) row_end = sc.rows_img;
 
-    for (uint32_t row_t = row_begin; row_t < row_end; row_t += (uint32_t)R) {
+    // HBM -> LDS, the whole tile in flight at once
+    auto issue = [&](uint32_t row_t) {
         const int rows_t = (int)((row_end - row_t) < (uint32_t)R ? (row_end - row_t) : (uint32_t)R);
         const long long f0 = s0 + (long long)row_t * K;      // first float of the tile
         const long long q0 = f0 >> 2;                         // aligned window start (slots)
         const int sh = (int)(f0 & 3);                         // dword shift of the tile inside the window
         const int wslots = (sh + rows_t * K + 3) >> 2;       // window slots, <= kTileFloats / 4
-        // ---- HBM -> LDS, whole tile in flight
-        __syncthreads();                                      // previous tile fully consumed
         long long nd = q_last - q0 + 1;                       // slots of the window that may be read as 16 bytes
         const int ndma = nd < wslots ? (int)(nd < 0 ? 0 : nd) : wslots;
 #pragma unroll
@@ -158,6 +160,13 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
             const int left = (int)(total - (q0 + ndma) * 4);
             if (tid < left) st.tile[ndma * 4 + tid] = sc.src[(q0 + ndma) * 4 + tid];
         }
+    };
+    if (row_begin < row_end) issue(row_begin);
+    for (uint32_t row_t = row_begin; row_t < row_end; row_t += (uint32_t)R) {
+        const int rows_t = (int)((row_end - row_t) < (uint32_t)R ? (row_end - row_t) : (uint32_t)R);
+        const long long f0 = s0 + (long long)row_t * K;
+        const int sh = (int)(f0 & 3);
+        const int wslots = (sh + rows_t * K + 3) >> 2;
         __syncthreads();                                      // waits for the DMA (vmcnt) and publishes the tile
         const float *tile = st.tile + sh;
 
@@ -223,12 +232,16 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
             const uint32_t e = st.hits[h];
             exact_bits((int)(e & 0xFFFu), e >> 12);
         }
-        __syncthreads();
+        __syncthreads();                                      // the tile is consumed
+        // The next tile's loads go out before the staged keys are flushed: the flush waits for a
+        // global atomic, and that wait and the loads' flight time then overlap.
+        const int staged = st.count;
         if (tid == 0) st.nhits = 0;
-        if (st.count >= kStage / 2) flush_candidates(st, p, b);
+        if (row_t + (uint32_t)R < row_end) issue(row_t + (uint32_t)R);
+        if (staged >= kStage / 2) flush_candidates(st, p, b, staged);
     }
     __syncthreads();
-    flush_candidates(st, p, b);
+    flush_candidates(st, p, b, st.count);
 }
 
 // ------------------------------------------------------------ wave-private variant

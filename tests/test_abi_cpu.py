@@ -57,6 +57,16 @@ def test_host_side_validation_needs_no_gpu():
     assert lib.yh_detect_workspace_bytes(ctypes.byref(cfg), 4, 1000, 100000, ctypes.byref(nbytes)) == _abi.YH_ERR_INVALID_ARG
     with pytest.raises(_abi.YhError):
         _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), 4, 0, ctypes.byref(nbytes)))
+    # the fused loss + gradient call checks its gradient arguments before it looks for a device
+    # (the addresses below are never dereferenced on the host)
+    scales = (ctypes.c_float * 4)(1., 1., 5., 1.)
+    heads = _abi.pointer_array([0x1000])
+    call = lambda gw, grads: lib.yh_loss_with_grad(ctypes.byref(cfg), heads, 0x2000, 4, 60, scales, 0.6, 0, 0x3000, 1 << 20,
+                                                   0x4000, None, None, None, gw, grads, None)
+    assert call(None, _abi.pointer_array([0x5000])) == _abi.YH_ERR_INVALID_ARG
+    assert call(0x6000, None) == _abi.YH_ERR_INVALID_ARG
+    assert call(0x6000, heads) == _abi.YH_ERR_INVALID_ARG and b'aliases' in lib.yh_last_error()
+    assert call(0x6000, _abi.pointer_array([0])) == _abi.YH_ERR_INVALID_ARG
 
 
 def test_no_cpu_fallback():

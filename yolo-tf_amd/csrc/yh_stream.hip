@@ -583,14 +583,23 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     int emitted = 0;                                          // candidates of this unit already written out
 
     auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : -INFINITY; };
+    // The objectness logits of a round are requested one round ahead: while a round's survivors
+    // are gathered and worked on, the next round's column reads are already in flight.
+    float obj_n[kRowsRound];
+#pragma unroll
+    for (int j = 0; j < kRowsRound; ++j)
+        obj_n[j] = (uint32_t)j < steps ? objectness(row_begin + (uint32_t)j * 64u + (uint32_t)lane) : -INFINITY;
     __syncthreads();
     for (uint32_t t = 0, round = 0; t < steps; t += kRowsRound, ++round) {
         int *qn = s_qn + round % 3u;
         // 1, 2: this round's rows; survivors into the queue
         float obj_l[kRowsRound];
 #pragma unroll
-        for (int j = 0; j < kRowsRound; ++j)
-            obj_l[j] = t + j < steps ? objectness(row_begin + (t + j) * 64u + (uint32_t)lane) : -INFINITY;
+        for (int j = 0; j < kRowsRound; ++j) {
+            obj_l[j] = obj_n[j];
+            const uint32_t tn = t + kRowsRound + (uint32_t)j;
+            obj_n[j] = tn < steps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : -INFINITY;
+        }
 #pragma unroll
         for (int j = 0; j < kRowsRound; ++j) {
             const unsigned long long mask = __ballot(obj_l[j] >= pf);

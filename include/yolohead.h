@@ -12,8 +12,9 @@
  *    is a DEVICE pointer owned by the caller unless marked "host";
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *    all work is enqueued on it and no entry point synchronises with the host;
- *  - the library holds no mutable global state; calls on different
- *    (device, stream, workspace) triples may run concurrently;
+ *  - calls on different (device, stream, workspace) triples may run
+ *    concurrently; the only process-wide state is the launch-plan tuning of
+ *    yh_set_tuning (never the process environment);
  *  - heads are the NHWC head tensors [B][H][W][P*(C+5)] fp32, one per scale,
  *    channel order per prior = C class logits, t_y, t_x, t_h, t_w, objectness
  *    (YOLOv3.py:95-102, YOLOv2.py:96-100); `heads` itself is a HOST array of
@@ -72,6 +73,30 @@ typedef struct yh_head_config {
 int yh_version(void);
 const char *yh_last_error(void);
 
+/* Launch-plan knobs of the streaming pass of yh_detect*, for benchmarks and
+ * tests that compare the kernel variants; 0 in a field = the built-in default.
+ * No counterpart in the reference.  Process-wide; set it while no call is in
+ * progress, and query workspace sizes afterwards: yh_detect_workspace_bytes
+ * depends on cfg, batch, the bounds and this tuning, and on nothing else.
+ *   detect_kernel   1: objectness-first rows kernel (default); 2: streaming
+ *                   kernels that read the whole head;
+ *   row_steps       rows kernel: steps of 64 rows per work unit (default 2);
+ *   stream_tile_kib streaming kernel: wave-private tiles of 4 or 8 KiB
+ *                   (default 8), anything else = workgroup tiles;
+ *   stream_buffers  wave-private tiles in flight per wavefront, 2..4 (default 3);
+ *   stream_units    wave-private variant: target number of work units per launch;
+ *   stream_blocks   workgroup-tile variant: target number of workgroups. */
+typedef struct yh_tuning {
+    int32_t detect_kernel;
+    int32_t row_steps;
+    int32_t stream_tile_kib;
+    int32_t stream_buffers;
+    int32_t stream_units;
+    int32_t stream_blocks;
+} yh_tuning;
+int yh_set_tuning(const yh_tuning *tuning);   /* NULL restores the defaults */
+int yh_get_tuning(yh_tuning *tuning);
+
 /* Number of visible HIP devices (host out).  YH_ERR_NO_DEVICE when the HIP
  * runtime reports none: there is no CPU fallback. */
 int yh_device_count(int32_t *count);
@@ -100,7 +125,7 @@ int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batc
  * num_classes * nms_max_boxes <= 4096) selects a single-launch form of the
  * candidates -> detections stage; larger capacities take a three-launch form.
  * Results are identical.  The size also depends on the launch plan of the
- * streaming pass, which the library derives from cfg and batch alone. */
+ * streaming pass, which the library derives from cfg, batch and yh_set_tuning. */
 int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch,
                               int32_t max_candidates, int32_t nms_max_boxes, size_t *bytes);
 

@@ -25,3 +25,11 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail('this test needs a HIP device; the path has no CPU fallback')
     return torch.device('cuda:0')
+
+
+@pytest.fixture
+def tuning():
+    """yh_set_tuning for the duration of a test; the defaults come back afterwards."""
+    from yolo_tf_amd import _abi
+    yield _abi.set_tuning
+    _abi.set_tuning()

@@ -194,12 +194,12 @@ def test_both_launch_shapes_agree(gpu, c_oracle):
 
 
 @pytest.mark.parametrize('cap,kernel', [(None, '1'), (2048, '1'), (5000, '1'), (None, '2'), (2048, '2')])
-def test_pipelined_submit_matches_detect(gpu, monkeypatch, cap, kernel):
+def test_pipelined_submit_matches_detect(gpu, tuning, cap, kernel):
     """yh_detect_pipelined: batch i streams while batch i-1 is selected inside the same
     launch (capacity 512), or right before it (larger capacities): detect()'s results,
     batch after batch, on alternating workspaces; with the objectness-first kernel (1) and
     with the streaming one (2)."""
-    monkeypatch.setenv('YH_DETECT_KERNEL', kernel)
+    tuning(detect_kernel=int(kernel))
     case = cases.v3()
     hd = case.head_obj()
     sets = [y.synth.torch_heads(gpu, 70 + i, 4, case.grids, case.P, case.C) for i in range(5)]
@@ -300,7 +300,7 @@ def test_candidates_then_select_calls(gpu):
     assert torch.equal(got.class_candidates, want.class_candidates)
 
 
-def test_streaming_variants_agree(gpu, monkeypatch):
+def test_streaming_variants_agree(gpu, tuning):
     """The objectness-first kernel (the default; one to several steps per work unit), the
     wave-private streaming kernel (4 and 8 KiB tiles, 2..4 buffers, few and many work units)
     and the workgroup-tile kernel find the same candidates."""
@@ -311,18 +311,14 @@ def test_streaming_variants_agree(gpu, monkeypatch):
     want, want_cc = ref.per_image(), ref.class_candidates.clone()
     assert int(ref.count.sum()) > 0
     for steps in ('1', '3', '50'):
-        monkeypatch.setenv('YH_ROW_STEPS', steps)
+        tuning(row_steps=int(steps))
         got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
         assert not got.overflowed()
         cases.same_detections(got.per_image(), want)
         assert torch.equal(got.class_candidates, want_cc)
-    monkeypatch.delenv('YH_ROW_STEPS')
-    monkeypatch.setenv('YH_DETECT_KERNEL', '2')
     for ni, nbuf, units in (('8', '3', '8192'), ('8', '2', '64'), ('4', '2', '300'), ('4', '3', '7'),
                             ('4', '4', '100000'), ('1', '3', '8192')):
-        monkeypatch.setenv('YH_STREAM_NI', ni)
-        monkeypatch.setenv('YH_STREAM_NBUF', nbuf)
-        monkeypatch.setenv('YH_STREAM_UNITS', units)
+        tuning(detect_kernel=2, stream_tile_kib=int(ni), stream_buffers=int(nbuf), stream_units=int(units))
         got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
         assert not got.overflowed()
         cases.same_detections(got.per_image(), want)
@@ -488,6 +484,66 @@ def test_threshold_edges(gpu, c_oracle):
     assert all(len(o[0]) == 0 for o in hd.detect(to_dev(heads, gpu), 1.5, 0.5, 5).per_image())
 
 
+@pytest.mark.parametrize('thr', [0.0, -1.0])
+def test_non_positive_threshold_on_the_rows_kernel(gpu, c_oracle, thr):
+    """thr <= 0 turns the objectness prefilter into -inf; with N * C <= 2048 the call stays on the
+    objectness-first kernel, whose lanes beyond a unit's rows must not pass that test: every
+    (box, class) pair of the image is a candidate, none beyond it, detections as the oracle's."""
+    case = cases.v2(C=2)                                       # 845 boxes x 2 classes = 1690 pairs
+    heads = case.heads(73, 3)
+    hd = case.head_obj()
+    res = hd.detect(to_dev(heads, gpu), thr, 0.5, 7, max_candidates=case.N * case.C, want_class_candidates=True)
+    assert not res.overflowed()
+    assert np.all(res.class_candidates.cpu().numpy() == case.N)
+    want = c_oracle.detect(case.oracle_cfg(c_oracle), heads, thr, 0.5, 7)
+    got = res.per_image()
+    cases.same_detections(got, want)
+    for g, w in zip(got, want):
+        assert_close(g[0], w[0], what='scores')
+        assert g[3].max() < case.N
+
+
+@pytest.mark.parametrize('mb', [512, 400])
+def test_nms_prefix_selection_at_the_largest_max_boxes(gpu, c_oracle, mb):
+    """nms_max_boxes 512 and class segments of 1640..2048 candidates: the radix-selected prefix of
+    the score order may not outgrow its LDS buffer (1024 keys); selections as the oracle's."""
+    rng = np.random.default_rng(23)
+    B, N, C = 2, 2048, 2
+    centre = rng.uniform(0, 3000, size=(B, N, 2)).astype(np.float32)
+    size = rng.uniform(20, 60, size=(B, N, 2)).astype(np.float32)
+    boxes = np.concatenate([centre - size / 2, centre + size / 2], axis=-1).astype(np.float32)
+    conf = rng.uniform(0.2, 1.0, size=(B, N, C)).astype(np.float32)
+    conf[1, 1700:, 1] = 0.0                                    # one segment of 1700
+    # scores bunched so that the first radix level's boundary bin overshoots the target
+    conf[0, :, 0] = (0.5 + 0.001 * rng.uniform(size=N)).astype(np.float32)
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    got = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), 0.1, 0.5, mb,
+                 max_candidates=N * C).per_image()
+    want = c_oracle.nms(boxes, conf, 0.1, 0.5, mb)
+    cases.same_detections(got, want)
+    assert max(len(g[0]) for g in got) > mb
+
+
+def test_loss_at_the_largest_ground_truth_block(gpu, c_oracle):
+    """pad 2048 (the documented bound): 90 KiB of LDS for the ground-truth block, beyond the
+    default limit of dynamic LDS."""
+    case = cases.v3(size=96, C=6)
+    B, pad, G = 2, 2048, 2040
+    heads = case.heads(83, B)
+    gt = case.gt(84, B, G, pad)
+    out = case.head_obj().loss(to_dev(heads, gpu), torch.from_numpy(gt).to(gpu), 1., 1., 5., 1., 0.5, True,
+                               want_parts=True, want_iou_max=True)
+    per, parts, iou, _ = c_oracle.loss(case.oracle_cfg(c_oracle), heads, gt, (1., 1., 5., 1.), 0.5, True, want_iou=True)
+    assert np.array_equal(out['iou_max'].cpu().numpy().view(np.uint32), iou.view(np.uint32))
+    assert_close(out['parts'].cpu().numpy(), parts, what='loss parts')
+    assert_close(out['per_image'].cpu().numpy(), per, what='per-image loss')
+    fast = case.head_obj().loss(to_dev(heads, gpu), torch.from_numpy(gt).to(gpu), 1., 1., 5., 1., 0.5, True)
+    assert torch.equal(fast['per_image'], out['per_image'])
+    with pytest.raises(y._abi.YhError) as e:
+        case.head_obj().loss(to_dev(heads, gpu), torch.from_numpy(case.gt(84, B, 5, 2049)).to(gpu), 1., 1., 5., 1., 0.5, True)
+    assert e.value.code == y._abi.YH_ERR_LIMIT
+
+
 @pytest.mark.parametrize('G,B', [(100, 4), (7, 3), (1, 2)])
 def test_loss_v3_matches_oracle(gpu, c_oracle, G, B):
     case = cases.v3()
@@ -576,7 +632,8 @@ def test_loss_and_grad_equals_the_autograd_path(gpu):
 
 @pytest.mark.parametrize('version,size,B,G,pad,exact', [
     ('v3', 416, 8, 60, 100, False), ('v3', 96, 3, 0, 3, False), ('v3', 160, 2, 5, 30, True),
-    ('v2', 416, 4, 1, 20, False), ('v3', 608, 2, 99, 100, False)])
+    ('v2', 416, 4, 1, 20, False), ('v3', 608, 2, 99, 100, False), ('v3', 160, 40, 7, 12, False),
+    ('v3', 96, 150, 3, 5, False)])
 def test_fused_loss_and_gradient_equal_the_two_calls(gpu, version, size, B, G, pad, exact):
     """yh_loss_with_grad (gradient written during the forward pass) against yh_loss_forward
     followed by yh_loss_backward: every output bit for bit, with few and many ground-truth

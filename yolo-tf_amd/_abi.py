@@ -43,6 +43,12 @@ class HeadConfig(ctypes.Structure):
     ]
 
 
+class Tuning(ctypes.Structure):
+    """struct yh_tuning; 0 = the built-in default."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('detect_kernel', 'row_steps', 'stream_tile_kib', 'stream_buffers',
+                                              'stream_units', 'stream_blocks')]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int32
 _F = ctypes.c_float
@@ -53,6 +59,8 @@ _PP = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     'yh_version': (ctypes.c_int, []),
     'yh_last_error': (ctypes.c_char_p, []),
+    'yh_set_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
+    'yh_get_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
     'yh_device_count': (ctypes.c_int, [ctypes.POINTER(_I)]),
     'yh_probe_read': (ctypes.c_int, [_P, ctypes.c_size_t, _P]),
     'yh_boxes_per_image': (ctypes.c_int, [_CFG, ctypes.POINTER(ctypes.c_int64)]),
@@ -81,6 +89,7 @@ SIGNATURES = {
 }
 
 _lib = None
+tuning_epoch = 0
 
 
 def load():
@@ -97,6 +106,20 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def set_tuning(**fields):
+    """yh_set_tuning: process-wide launch-plan knobs (no arguments = defaults)."""
+    global tuning_epoch
+    t = Tuning(**{k: int(v) for k, v in fields.items()})
+    check(load().yh_set_tuning(ctypes.byref(t)))
+    tuning_epoch += 1                     # cached launch plans and workspace sizes are stale now
+
+
+def get_tuning():
+    t = Tuning()
+    check(load().yh_get_tuning(ctypes.byref(t)))
+    return {n: getattr(t, n) for n, _ in Tuning._fields_}
 
 
 def check(rc):

@@ -1,12 +1,14 @@
 // extern "C" boundary of libyolohead: argument checks, workspace carving and
 // kernel sequencing.  Declarations and the reference regions each entry point
 // replaces: include/yolohead.h.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include "yh_internal.h"
 
 namespace {
@@ -92,33 +94,39 @@ struct DetectWs {
     float *boxes, *cand_box, *uboxes;
     int32_t *img_count, *seg_off, *seg_cnt, *class_hist, *class_cursor, *kept_cnt, *kept_row;
     float *kept_score;
+    size_t zero_begin, zero_bytes;
     size_t bytes;
 };
 
-// with_boxes: the workspace also holds the decoded boxes [B][N][4] and the
-// slot-indexed candidate boxes; upi: work units per image with private slots
-DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, int64_t mb, bool with_boxes,
-                      int64_t upi)
+// row_boxes: the workspace holds the decoded boxes by box row [B][N][4] (the workgroup-tile
+// streaming kernel writes them, the multi-launch select stage reads them); cand_boxes: it holds
+// the list entries' boxes [B][cap][4]; upi: work units per image with private slots.
+// [zero_begin, zero_begin + zero_bytes): the counters a call expects to find zero (a zero-filled
+// workspace has them so, and every call leaves them so).
+DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, int64_t mb, bool row_boxes,
+                      bool cand_boxes, int64_t upi)
 {
     DetectWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     char *p = static_cast<char *>(base);
     const size_t o_cand = take((size_t)B * cap * 8), o_seg = take((size_t)B * cap * 8);
-    const size_t o_box = with_boxes ? take((size_t)B * N * 16) : 0;
-    const size_t o_cbox = with_boxes ? take((size_t)B * cap * 16) : 0;
+    const size_t o_box = row_boxes ? take((size_t)B * N * 16) : 0;
+    const size_t o_cbox = cand_boxes ? take((size_t)B * cap * 16) : 0;
     const size_t o_uk = take((size_t)B * upi * yh::kUnitSlots * 8);
     const size_t o_ub = take((size_t)B * upi * yh::kUnitSlots * 16);
-    w.cand_box = with_boxes ? reinterpret_cast<float *>(p + o_cbox) : nullptr;
+    w.cand_box = cand_boxes ? reinterpret_cast<float *>(p + o_cbox) : nullptr;
     w.ukeys = reinterpret_cast<unsigned long long *>(p + o_uk);
     w.uboxes = reinterpret_cast<float *>(p + o_ub);
-    const size_t o_img = take((size_t)B * 4);
     const size_t o_off = take((size_t)B * C * 4), o_cnt = take((size_t)B * C * 4);
+    const size_t o_img = take((size_t)B * 4);
     const size_t o_hist = take((size_t)B * C * 4), o_cur = take((size_t)B * C * 4);
     const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
+    w.zero_begin = o_img;
+    w.zero_bytes = o_kc - o_img;                 // img_count, class_hist, class_cursor
     w.cand = reinterpret_cast<unsigned long long *>(p + o_cand);
     w.seg_keys = reinterpret_cast<unsigned long long *>(p + o_seg);
-    w.boxes = with_boxes ? reinterpret_cast<float *>(p + o_box) : nullptr;
+    w.boxes = row_boxes ? reinterpret_cast<float *>(p + o_box) : nullptr;
     w.img_count = reinterpret_cast<int32_t *>(p + o_img);
     w.seg_off = reinterpret_cast<int32_t *>(p + o_off);
     w.seg_cnt = reinterpret_cast<int32_t *>(p + o_cnt);
@@ -129,6 +137,15 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     w.kept_score = reinterpret_cast<float *>(p + o_ks);
     w.bytes = off;
     return w;
+}
+
+// yh_detect's workspace for a streaming plan: the slot-writing kernels followed by the
+// single-launch select stage never touch the boxes-by-row array, the largest part by far.
+DetectWs carve_for_plan(void *base, const yh::StreamParams &p, int64_t B, int64_t cap, int64_t mb)
+{
+    const bool slots = p.wave_ni || p.row_gather;
+    const bool row_boxes = !slots || !yh::select_single_launch((int)cap, p.C, (int)mb);
+    return carve_detect(base, B, p.N, p.C, cap, mb, row_boxes, slots, p.upi);
 }
 
 int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_cand, const void *ws,
@@ -153,11 +170,14 @@ constexpr uint64_t kStreamTargetBlocks = 3600;
 
 constexpr uint64_t kStreamTargetUnits = 8192;   // wave-private variant: work units (one per wavefront)
 
-long env_knob(const char *name, long fallback)
+// Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
+// relaxed atomics; 0 = the built-in default.
+std::atomic<int32_t> g_tuning[6];
+enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks };
+
+long knob(int which, long fallback)
 {
-    const char *e = std::getenv(name);
-    if (!e) return fallback;
-    const long v = std::atol(e);
+    const long v = g_tuning[which].load(std::memory_order_relaxed);
     return v > 0 ? v : fallback;
 }
 
@@ -172,10 +192,10 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
     p.units = 0;
     if (mode == yh::kModeDetect && max_candidates <= yh::kPostCap) {
         // tuning knob: 1 = objectness-first variant (default), 2 = streaming variants
-        if (env_knob("YH_DETECT_KERNEL", 1) == 1) {
+        if (knob(kTuneDetectKernel, 1) == 1) {
             p.row_gather = 1;
         } else {
-            const long ni = env_knob("YH_STREAM_NI", 8);         // tuning knob: 4, 8, anything else = workgroup tiles
+            const long ni = knob(kTuneStreamNi, 8);         // tuning knob: 4, 8, anything else = workgroup tiles
             if ((ni == 4 || ni == 8) && (256 * ni - 3) / p.K >= 1) p.wave_ni = (int32_t)ni;
             else if (ni == 4 && (256 * 8 - 3) / p.K >= 1) p.wave_ni = 8;
         }
@@ -186,7 +206,7 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         // ones); an image's units are indexed by the candidates -> detections stage, so their
         // number is bounded
         const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
-        uint64_t steps = (uint64_t)env_knob("YH_ROW_STEPS", 2);
+        uint64_t steps = (uint64_t)knob(kTuneRowSteps, 2);
         for (;; ++steps) {
             uint64_t upi = 0;
             for (int s = 0; s < p.S; ++s) upi += ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
@@ -207,13 +227,13 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         return p.units * (uint32_t)B;
     }
     if (p.wave_ni) {
-        const long nb = env_knob("YH_STREAM_NBUF", 3);
+        const long nb = knob(kTuneStreamNbuf, 3);
         p.wave_nbuf = (nb >= 2 && nb <= (p.wave_ni == 4 ? 4 : 3)) ? (int32_t)nb : 3;
         p.tile_rows = (256 * p.wave_ni - 3) / p.K;
         uint64_t total_tiles = 0;
         for (int s = 0; s < p.S; ++s)
             total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
-        const uint64_t want = (uint64_t)env_knob("YH_STREAM_UNITS", (long)kStreamTargetUnits);
+        const uint64_t want = (uint64_t)knob(kTuneStreamUnits, (long)kStreamTargetUnits);
         uint64_t tpc = (total_tiles + want / 2) / want;          // tiles per wavefront, nearest
         if (tpc < 1) tpc = 1;
         // an image's units are indexed by the candidates -> detections stage: bounded
@@ -238,7 +258,7 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
     uint64_t total_tiles = 0;
     for (int s = 0; s < p.S; ++s)
         total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
-    const uint64_t want = (uint64_t)env_knob("YH_STREAM_BLOCKS", (long)kStreamTargetBlocks);   // tuning knob
+    const uint64_t want = (uint64_t)knob(kTuneStreamBlocks, (long)kStreamTargetBlocks);   // tuning knob
     uint64_t tpc = (total_tiles + want / 2) / want;              // tiles per workgroup, nearest
     if (tpc < 1) tpc = 1;
     if (tpc > 64) tpc = 64;
@@ -296,7 +316,29 @@ int ensure_device()
 
 extern "C" {
 
-int yh_version(void) { return 100; }
+int yh_version(void) { return 200; }
+
+int yh_set_tuning(const yh_tuning *t)
+{
+    const int32_t v[6] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
+                          t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0};
+    for (int i = 0; i < 6; ++i)
+        if (v[i] < 0) return fail(YH_ERR_INVALID_ARG, "tuning field %d is negative", i);
+    for (int i = 0; i < 6; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
+    return YH_OK;
+}
+
+int yh_get_tuning(yh_tuning *t)
+{
+    if (!t) return fail(YH_ERR_INVALID_ARG, "tuning is null");
+    t->detect_kernel = g_tuning[kTuneDetectKernel].load(std::memory_order_relaxed);
+    t->row_steps = g_tuning[kTuneRowSteps].load(std::memory_order_relaxed);
+    t->stream_tile_kib = g_tuning[kTuneStreamNi].load(std::memory_order_relaxed);
+    t->stream_buffers = g_tuning[kTuneStreamNbuf].load(std::memory_order_relaxed);
+    t->stream_units = g_tuning[kTuneStreamUnits].load(std::memory_order_relaxed);
+    t->stream_blocks = g_tuning[kTuneStreamBlocks].load(std::memory_order_relaxed);
+    return YH_OK;
+}
 
 const char *yh_last_error(void) { return g_err; }
 
@@ -367,8 +409,7 @@ int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t 
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, nullptr, batch);
     if (batch > 0) plan_stream(p, batch, yh::kModeDetect, max_candidates);
-    *bytes = carve_detect(nullptr, batch, boxes_per_image(cfg), cfg->num_classes, max_candidates,
-                          nms_max_boxes, true, p.upi).bytes;
+    *bytes = carve_for_plan(nullptr, p, batch, max_candidates, nms_max_boxes).bytes;
     return YH_OK;
 }
 
@@ -379,7 +420,7 @@ int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_img, int32_t num_cla
     if (batch < 0 || boxes_per_img < 1 || num_classes < 1 || max_candidates < 1 || nms_max_boxes < 1 ||
         nms_max_boxes > YH_MAX_NMS_BOXES)
         return fail(YH_ERR_INVALID_ARG, "bad size argument");
-    *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, 0).bytes;
+    *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, false, 0).bytes;
     return YH_OK;
 }
 
@@ -422,6 +463,7 @@ struct DetectPlan {
     yh::StreamParams p;
     yh::NmsParams q;
     uint32_t blocks;
+    size_t zero_begin, zero_bytes;      // the workspace's counters (DetectWs)
 };
 
 static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float *const *heads, bool want_stream,
@@ -450,10 +492,12 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
     yh::StreamParams &p = d.p;
     fill_stream_from_config(p, cfg, want_stream ? heads : nullptr, batch);
     d.blocks = plan_stream(p, batch, yh::kModeDetect, max_candidates);
-    const DetectWs w = carve_detect(workspace, batch, N, cfg->num_classes, max_candidates, nms_max_boxes, true, p.upi);
+    const DetectWs w = carve_for_plan(workspace, p, batch, max_candidates, nms_max_boxes);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
+    d.zero_begin = w.zero_begin;
+    d.zero_bytes = w.zero_bytes;
 
     p.thr = score_threshold;
     p.prefilter = prefilter_logit(score_threshold);
@@ -609,7 +653,7 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     if ((reinterpret_cast<uintptr_t>(boxes) & 15u) || (reinterpret_cast<uintptr_t>(conf) & 15u) ||
         (reinterpret_cast<uintptr_t>(out_boxes) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(YH_ERR_ALIGN, "boxes / conf / out_boxes must be 16-byte and workspace 256-byte aligned");
-    const DetectWs w = carve_detect(workspace, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, 0);
+    const DetectWs w = carve_detect(workspace, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, false, 0);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
     if ((rc = ensure_device()) != YH_OK) return rc;
@@ -683,11 +727,19 @@ static int check_loss_sizes(const yh_head_config *cfg, int32_t batch, int32_t pa
 {
     if (batch < 0) return fail(YH_ERR_INVALID_ARG, "batch %d is negative", batch);
     if (pad < 1 || pad > 2048) return fail(YH_ERR_LIMIT, "pad %d outside [1, 2048]", pad);
+    int occ_words = 0;
     for (int s = 0; s < cfg->num_scales; ++s) {
         if (!(cfg->gt_rate[s] > 0.0f)) return fail(YH_ERR_INVALID_ARG, "gt_rate[%d] must be positive", s);
         if ((int64_t)cfg->grid_h[s] * cfg->grid_w[s] > (1 << 18))
             return fail(YH_ERR_LIMIT, "grid %d has more than 2^18 cells", s);
+        const int w = (cfg->grid_h[s] * cfg->grid_w[s] + 31) >> 5;
+        occ_words = w > occ_words ? w : occ_words;
     }
+    // the ground-truth block and the occupancy bitmap of the largest grid share a workgroup's LDS
+    const size_t lds = yh::loss_lds_bytes(pad, occ_words) + 1024;
+    if (lds > yh::kLdsPerWorkgroupMax)
+        return fail(YH_ERR_LIMIT, "pad %d with a grid of %d cells needs %zu bytes of LDS, %zu available", pad,
+                    occ_words * 32, lds, yh::kLdsPerWorkgroupMax);
     return YH_OK;
 }
 

@@ -93,6 +93,10 @@ struct StreamParams {
     StreamScale sc[YH_MAX_SCALES];
 };
 
+// Raises a kernel's dynamic-LDS limit on the current device when `bytes` needs it (cached).
+hipError_t raise_lds_limit(const void *kernel, size_t bytes);
+constexpr size_t kLdsPerWorkgroupMax = 160 * 1024;   // LDS of one gfx950 compute unit
+
 hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t st);
 
 constexpr int kTileFloats = 5120;                   // LDS tile of the streaming pass: 20 KiB
@@ -146,6 +150,7 @@ constexpr int kPostThreads = 1024;      // workgroup of the stand-alone kernel
 constexpr size_t kFuseLdsMax = 32 * 1024;   // largest LDS block of the stage when it rides in the streaming launch
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
+bool select_single_launch(int cand_cap, int num_classes, int max_boxes);   // k_post takes the whole stage
 bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
 bool select_fits_rows(const NmsParams &p);     // ... in a launch of the objectness-first variant
 constexpr int kRowsThreads = 512;           // objectness-first variant: eight wavefronts per workgroup
@@ -184,6 +189,7 @@ struct LossParams {
 };
 
 hipError_t launch_loss(const LossParams &p, hipStream_t st);
+size_t loss_lds_bytes(int pad, int occ_words);      // dynamic LDS of the loss kernel: GT block + occupancy bitmap
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;

@@ -460,10 +460,14 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
 // ---------------------------------------------------------------- finalize
 // One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
 // the batch sum.  Sixteen lanes per image (64 images at a time with 1024 threads): they
-// fetch the image's partial sums together and add them up in double in a fixed tree, so
-// the result depends neither on scheduling nor on the workgroup's size.
+// fetch the image's partial sums together and add them up in double in a fixed tree.  The
+// batch sum is defined over kFinalizeClasses residue classes of the image index (class g
+// adds the losses of images g, g + 64, ... in that order, then the classes are added in
+// order), whatever the workgroup's size: a smaller workgroup keeps several classes per lane
+// group.  The result depends neither on scheduling nor on the workgroup's size.
 constexpr int kFinalizeThreads = 1024;
 constexpr int kFinalizeLanes = 16;
+constexpr int kFinalizeClasses = 64;
 
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -476,9 +480,13 @@ template <int THREADS>
 __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum)
 {
     constexpr int kFinalizeGroups = THREADS / kFinalizeLanes;
+    constexpr int kPerGroup = kFinalizeClasses / kFinalizeGroups;   // residue classes a lane group carries
+    static_assert(kFinalizeGroups * kPerGroup == kFinalizeClasses, "the lane groups split the residue classes evenly");
     const int tid = threadIdx.x, gl = tid & (kFinalizeLanes - 1), grp = tid / kFinalizeLanes;
-    double local = 0.0;                                        // lane 0 of each group: its images' losses
-    for (int b = grp; b < p.B; b += kFinalizeGroups) {
+    double local[kPerGroup];                                   // lane 0 of each group: its images' losses
+#pragma unroll
+    for (int k = 0; k < kPerGroup; ++k) local[k] = 0.0;
+    for (int b = grp, turn = 0; b < p.B; b += kFinalizeGroups, ++turn) {
         double coord = 0.0, cls = 0.0, obj = 0.0, noobj = 0.0;
         const float gf = p.normalize ? (float)p.gcount[b] : 1.0f;
         const float *pp = p.pos_partial + (long long)b * p.pos_blocks * 3;
@@ -497,14 +505,19 @@ __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum
                 p.loss_parts[b * 4 + 0] = fc; p.loss_parts[b * 4 + 1] = fk;
                 p.loss_parts[b * 4 + 2] = fo; p.loss_parts[b * 4 + 3] = fn;
             }
-            local += (double)li;
+#pragma unroll
+            for (int k = 0; k < kPerGroup; ++k)               // image b belongs to class b mod 64 = grp + 16 * (turn mod kPerGroup)
+                if (turn % kPerGroup == k) local[k] += (double)li;
         }
     }
-    if (gl == 0) s_sum[grp] = local;
+    if (gl == 0) {
+#pragma unroll
+        for (int k = 0; k < kPerGroup; ++k) s_sum[grp + k * kFinalizeGroups] = local[k];
+    }
     __syncthreads();
     if (tid == 0 && p.loss_sum) {
         double acc = 0.0;
-        for (int g = 0; g < kFinalizeGroups; ++g) acc += s_sum[g];
+        for (int g = 0; g < kFinalizeClasses; ++g) acc += s_sum[g];
         p.loss_sum[0] = (float)acc;
         p.loss_sum[1] = (float)acc / (float)p.B;              // reduce_mean over this call's images, in fp32
     }
@@ -512,7 +525,7 @@ __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum
 
 __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
 {
-    __shared__ double s_sum[kFinalizeThreads / kFinalizeLanes];
+    __shared__ double s_sum[kFinalizeClasses];
     loss_finalize<kFinalizeThreads>(p, s_sum);
 }
 
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos_finalize(const Lo
 {
     __shared__ float s_val[kPosThreads / 64];
     __shared__ int s_idx[kPosThreads / 64];
-    __shared__ double s_sum[kPosThreads / kFinalizeLanes];
+    __shared__ double s_sum[kFinalizeClasses];
     if (blockIdx.x + 1u == gridDim.x) loss_finalize<kPosThreads>(p, s_sum);
     else loss_grad_pos(p, blockIdx.x, s_val, s_idx);
 }
@@ -646,6 +659,12 @@ hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
     return hipGetLastError();
 }
 
+size_t loss_lds_bytes(int pad, int occ_words)
+{
+    return (size_t)((pad + 1) / 2) * kPairStride * sizeof(float) + (size_t)pad * 5 * sizeof(float) +
+           (size_t)occ_words * sizeof(uint32_t);
+}
+
 hipError_t launch_loss(const LossParams &p, hipStream_t stm)
 {
     if (p.B == 0) return hipSuccess;
@@ -654,18 +673,15 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
         if (w > occ_words) occ_words = w;
     }
-    const size_t lds = (size_t)((p.pad + 1) / 2) * kPairStride * sizeof(float) + (size_t)p.pad * 5 * sizeof(float) +
-                       (size_t)occ_words * sizeof(uint32_t);
+    const size_t lds = loss_lds_bytes(p.pad, occ_words);
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
     const bool grad = p.grad_w != nullptr;                     // forward and gradient in one pass over the rows
-    if (p.iou_max) {
-        if (grad) hipLaunchKernelGGL((k_loss_main<true, true>), grid, dim3(kLossNegThreads), lds, stm, p);
-        else hipLaunchKernelGGL((k_loss_main<true, false>), grid, dim3(kLossNegThreads), lds, stm, p);
-    } else {
-        if (grad) hipLaunchKernelGGL((k_loss_main<false, true>), grid, dim3(kLossNegThreads), lds, stm, p);
-        else hipLaunchKernelGGL((k_loss_main<false, false>), grid, dim3(kLossNegThreads), lds, stm, p);
-    }
-    const hipError_t e = hipGetLastError();
+    void (*kernel)(const LossParams) = p.iou_max ? (grad ? k_loss_main<true, true> : k_loss_main<true, false>)
+                                                 : (grad ? k_loss_main<false, true> : k_loss_main<false, false>);
+    hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(kernel), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), lds, stm, p);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (grad)
         hipLaunchKernelGGL(k_loss_grad_pos_finalize, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks + 1u), dim3(kPosThreads), 0, stm, p);

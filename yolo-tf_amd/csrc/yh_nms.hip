@@ -241,8 +241,8 @@ __device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, i
         d2 = s_ctl[0];
         n = s_ctl[1];
         __syncthreads();
-        if (n > kSelMax) return 0;
     }
+    if (n > kSelMax) return 0;                              // s_sel holds kSelMax keys
     for (int i = tid; i < cnt; i += kSegThreads) {
         const unsigned long long k = s_keys[i];
         const int b1 = (int)(k >> kShift1) & 0xFF, b2 = (int)(k >> kShift2) & 0xFF;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         __syncthreads();
         // a prefix of about 240 keys sorts as 256 (the selection overshoots its target by a few keys)
         const int target = 2 * p.max_boxes > 240 ? 2 * p.max_boxes : 240;
-        if (cnt >= 2 * target && target <= kSelMax) {
+        if (cnt >= 2 * target && target + (target >> 2) <= kSelMax) {
             const int n = select_prefix(s_keys, cnt, target, s_sel, s_hist, s_ctl);
             if (n > 0) {
                 int n2 = 128;
@@ -445,11 +445,13 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int
     if (part == 0 && tid == 0) p.out_count[b] = s_off[C - 1] + kept[C - 1];
 }
 
-static bool single_launch_shape(const NmsParams &p)
+bool select_single_launch(int cand_cap, int num_classes, int max_boxes)
 {
-    return p.cand_cap <= kPostCap && p.C <= kPostMaxClasses && p.max_boxes <= kPostMaxBoxes &&
-           p.C * p.max_boxes <= kPostKeptMax;
+    return cand_cap <= kPostCap && num_classes <= kPostMaxClasses && max_boxes <= kPostMaxBoxes &&
+           num_classes * max_boxes <= kPostKeptMax;
 }
+
+static bool single_launch_shape(const NmsParams &p) { return select_single_launch(p.cand_cap, p.C, p.max_boxes); }
 
 bool select_fits_stream(const NmsParams &p)
 {
@@ -466,11 +468,8 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     if (p.B == 0) return hipSuccess;
     if (single_launch_shape(p)) {
         const size_t lds = post_layout(p.cand_cap, p.C, p.max_boxes, kPostThreads).bytes;
-        if (lds > 48 * 1024) {                // beyond the default limit of dynamic LDS
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_post),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
+        const hipError_t le = raise_lds_limit(reinterpret_cast<const void *>(k_post), lds);
+        if (le != hipSuccess) return le;
         hipLaunchKernelGGL(k_post, dim3(p.B), dim3(kPostThreads), lds, stm, p);
         return hipGetLastError();
     }

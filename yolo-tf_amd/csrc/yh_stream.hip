@@ -29,6 +29,7 @@
 // reads the whole head without barriers) and k_detect_rows (objectness-first:
 // does not read the whole head; the default of yh_detect).
 #include <cstring>
+#include <mutex>
 #include "yh_post.h"
 
 namespace yh {
@@ -58,7 +59,7 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
         st.keys[slot] = key;
     } else {
         const int g = atomicAdd(&p.img_count[b], 1);
-        if (g < p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = key;
+        if ((uint32_t)g < (uint32_t)p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = key;
     }
 }
 
@@ -103,7 +104,7 @@ __device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &
         const int base = st.base;
         for (int i = tid; i < cnt; i += kThreads) {
             const int g = base + i;
-            if (g < p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
+            if ((uint32_t)g < (uint32_t)p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
         }
         __syncthreads();
         if (tid == 0) st.count = 0;
@@ -373,7 +374,7 @@ __device__ __forceinline__ void wave_flush(const WaveOut &o, const unsigned long
             o.uboxes[emitted + i] = boxes[i];
         } else {
             const int g = base + (i - n_unit);
-            if (g < o.cand_cap) {
+            if ((uint32_t)g < (uint32_t)o.cand_cap) {
                 o.cand[g] = keys[i];
                 o.cand_box[g] = boxes[i];
             }
@@ -582,13 +583,15 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     int count = 0;                                            // staged candidates, wave-uniform
     int emitted = 0;                                          // candidates of this unit already written out
 
-    auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : -INFINITY; };
+    // rows outside the unit read as NaN: no comparison with the prefilter (-inf for thr <= 0) holds for them
+    const float kNoRow = __builtin_nanf("");
+    auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : kNoRow; };
     // The objectness logits of a round are requested one round ahead: while a round's survivors
     // are gathered and worked on, the next round's column reads are already in flight.
     float obj_n[kRowsRound];
 #pragma unroll
     for (int j = 0; j < kRowsRound; ++j)
-        obj_n[j] = (uint32_t)j < steps ? objectness(row_begin + (uint32_t)j * 64u + (uint32_t)lane) : -INFINITY;
+        obj_n[j] = (uint32_t)j < steps ? objectness(row_begin + (uint32_t)j * 64u + (uint32_t)lane) : kNoRow;
     __syncthreads();
     for (uint32_t t = 0, round = 0; t < steps; t += kRowsRound, ++round) {
         int *qn = s_qn + round % 3u;
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
         for (int j = 0; j < kRowsRound; ++j) {
             obj_l[j] = obj_n[j];
             const uint32_t tn = t + kRowsRound + (uint32_t)j;
-            obj_n[j] = tn < steps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : -INFINITY;
+            obj_n[j] = tn < steps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
         }
 #pragma unroll
         for (int j = 0; j < kRowsRound; ++j) {
@@ -677,6 +680,31 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and size: the
+// largest value asked for so far is remembered, a launch within it costs no runtime call.
+hipError_t raise_lds_limit(const void *kernel, size_t bytes)
+{
+    constexpr int kSlots = 32, kDevices = 64;
+    static std::mutex mu;
+    static const void *fn[kSlots];
+    static size_t limit[kSlots][kDevices];
+    if (bytes <= 48 * 1024) return hipSuccess;                // the default limit of dynamic LDS
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    int at = -1;
+    for (int i = 0; i < kSlots && at < 0; ++i)
+        if (fn[i] == kernel || fn[i] == nullptr) at = i;
+    if (at < 0) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    fn[at] = kernel;
+    if (limit[at][dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) limit[at][dev] = bytes;
+    return e;
+}
+
 static hipError_t launch_rows(const StreamParams &p, uint32_t blocks, hipStream_t stm, const NmsParams &q)
 {
     size_t lds = kRowsLds;
@@ -684,11 +712,8 @@ static hipError_t launch_rows(const StreamParams &p, uint32_t blocks, hipStream_
         const size_t need = post_layout(q.cand_cap, q.C, q.max_boxes, kRowsThreads).bytes;
         lds = need > lds ? need : lds;
     }
-    if (lds > 48 * 1024) {                    // beyond the default limit of dynamic LDS
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_detect_rows),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    const hipError_t le = raise_lds_limit(reinterpret_cast<const void *>(k_detect_rows), lds);
+    if (le != hipSuccess) return le;
     hipLaunchKernelGGL(k_detect_rows, dim3(blocks + (uint32_t)q.B), dim3(kRowsThreads), lds, stm, p, q);
     return hipGetLastError();
 }
@@ -722,11 +747,8 @@ static hipError_t launch_wave(const StreamParams &p, uint32_t blocks, hipStream_
         const size_t need = post_layout(q.cand_cap, q.C, q.max_boxes, 64).bytes;
         lds = need > lds ? need : lds;
     }
-    if (lds > 48 * 1024) {                    // beyond the default limit of dynamic LDS
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stream_wave<NI, NBUF>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    const hipError_t le = raise_lds_limit(reinterpret_cast<const void *>(k_stream_wave<NI, NBUF>), lds);
+    if (le != hipSuccess) return le;
     hipLaunchKernelGGL((k_stream_wave<NI, NBUF>), dim3(blocks + (uint32_t)q.B), dim3(64), lds, stm, p, q);
     return hipGetLastError();
 }

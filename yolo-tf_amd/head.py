@@ -182,7 +182,7 @@ class DetectionHead:
         """(cfg, B, N, workspace) for these head shapes and bounds, planned once;
         `slot` distinguishes workspaces of batches that are in flight together."""
         dev = heads[0].device
-        key = ('detect', tuple(tuple(h.shape) for h in heads), cap, int(max_boxes), dev, slot)
+        key = ('detect', tuple(tuple(h.shape) for h in heads), cap, int(max_boxes), dev, slot, _abi.tuning_epoch)
         plan = self._plans.get(key)
         if plan is None:
             lib = _abi.load()
@@ -305,11 +305,13 @@ class DetectionHead:
         if gt.dim() != 3 or gt.shape[0] != B or gt.shape[2] != 5:
             raise ValueError('ground_truth must be [B, pad, 5]')
         pad = int(gt.shape[1])
-        ws = self._ws.get(('loss', B, N, pad))
+        # keyed by the grid shapes: the size depends on the per-scale split of the rows, not on N alone
+        wkey = ('loss', tuple(tuple(h.shape) for h in heads), pad)
+        ws = self._ws.get(wkey)
         if ws is None or ws.device != dev:
             nbytes = ctypes.c_size_t(0)
             _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
-            ws = self._workspace(('loss', B, N, pad), nbytes.value, dev)
+            ws = self._workspace(wkey, nbytes.value, dev)
         if (out is not None and out['per_image'].shape == (B,) and out['per_image'].device == dev and
                 (out['parts'] is not None) == want_parts and (out['iou_max'] is not None) == want_iou_max and
                 (out['noobj_mask'] is not None) == want_mask and
@@ -463,7 +465,9 @@ class DetectPipeline:
         prev = self._prev
         if rec is None or prev is None:
             return None
-        shapes, dev, cap, prev_ws, prev_outputs, args, arr, mine, default_for = rec
+        shapes, dev, cap, prev_ws, prev_outputs, args, arr, mine, default_for, epoch = rec
+        if epoch != _abi.tuning_epoch:
+            return None
         # the prepared arguments hold the addresses of exactly these tensors
         if prev[2] is not prev_ws or prev[3] is not prev_outputs or self._outputs[slot] is not mine[3]:
             return None
@@ -523,7 +527,7 @@ class DetectPipeline:
         self._prev = (cfg, B, ws, self._outputs[slot], dev, cap)
         if prev is not None and stream_events is None:
             self._steady[slot] = (tuple(h.shape for h in heads), dev, cap, prev[2], prev[3], args, arr,
-                                  self._prev, N)
+                                  self._prev, N, _abi.tuning_epoch)
         self._i += 1
         return done
 

@@ -211,24 +211,27 @@ class YOLOv3:
         print(datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S.%f'))
         return pred
 
+    def _provider_hook(self, name):
+        """The head provider's save / load / load_pretraining; the weights live there, not in this
+        path, so without the hook nothing can be written or read and saying "successfully" would lie."""
+        fn = getattr(self.head_provider, name, None)
+        if fn is None:
+            raise RuntimeError('the head provider %r has no %s(path): there are no weights to %s'
+                               % (type(self.head_provider).__name__, name, name.split('_')[0]))
+        return fn
+
     def save_weight(self, mode, path):
         assert(mode in ['latest', 'best'])
         if os.path.dirname(path) and not os.path.exists(os.path.dirname(path)):
             os.makedirs(os.path.dirname(path))
             print(os.path.dirname(path), 'does not exist, create it done')
-        fn = getattr(self.head_provider, 'save', None)
-        if fn is not None:
-            fn('%s-%d' % (path, self.global_step))
+        self._provider_hook('save')('%s-%d' % (path, self.global_step))
         print('save', mode, 'model in', path, 'successfully')
 
     def load_weight(self, path):
-        fn = getattr(self.head_provider, 'load', None)
-        if fn is not None:
-            fn(path)
+        self._provider_hook('load')(path)
         print('load weight', path, 'successfully')
 
     def load_pretraining_weight(self, path):
-        fn = getattr(self.head_provider, 'load_pretraining', None)
-        if fn is not None:
-            fn(path)
+        self._provider_hook('load_pretraining')(path)
         print('load pretraining weight', path, 'successfully')

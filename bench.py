@@ -15,19 +15,37 @@ Workloads (BASELINE.json configs):
   train416   config 3 with the backward to the head tensors (reads the head twice, writes its gradient)
   detect_v2  config 1  YOLOv2-416 VOC-20, batch 1 (latency-bound: one image)
   detect608  config 4  YOLOv3-608 COCO-80, batch 64 / GPU
-  stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 16 / GPU
+  stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 128 / GPU
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the pass
-over the head tensor: objectness-first by default, which does not read the
-whole tensor, so `achieved` = algorithmic bytes / time can exceed the peak and
-`traffic` tells what was read) with HIP events recorded around it on the
-launch stream inside the timed region; `cpu_baseline` times the C restatement
-of the reference's arithmetic (oracle/, "port") on this host's cores for a
-bounded sample of the same workload (rank 0, N = 1 only).
+Rank 0 prints ONE JSON line.
+
+`value` / `ms_per_step` come from the first timed region of exactly K steps (barrier and device
+synchronisation on both sides, maximum over ranks); `timing` adds the percentiles over that region
+and several more of the same length.
+
+`roofline` prices the dominant kernel, the pass over the head tensor:
+  kernel_ms        its average launch duration, HIP events on the launch stream, launches back to
+                   back on ONE stream (what a kernel trace shows);
+  traffic          HBM bytes per launch from the committed rocprofv3 PMC pass of this (workload,
+                   kernel) (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction,
+                   plus WRITE_SIZE), null when no pass is committed;
+  achieved, frac   traffic / kernel_ms, and that over the 8 TB/s peak: a statement about the memory
+                   system, at most 1 (with no PMC pass the bytes come from `traffic_model`);
+  algorithmic_*    the figure that prices N*(C+5)*4 bytes per image whatever the kernel reads.  The
+                   default detect kernel is objectness-first: it reads one cache line per row and only
+                   the rows whose objectness can still reach the score threshold, so this figure
+                   exceeds the peak at a detector's survival rate and depends on the data:
+                   `row_survival` says how many rows survived, `survival_sweep` shows the kernel from
+                   2 % to 100 % survival.
+`cpu_baseline` times the C restatement of the reference's arithmetic (oracle/, "port") on this
+host's cores for bounded samples of the same workload (rank 0, N = 1 only): all cores (OpenMP over
+images), one thread, and the NumPy restatement.
 """
 import argparse
+import ctypes
 import gc
 import json
+import math
 import os
 import sys
 import time
@@ -41,9 +59,9 @@ sys.path.insert(0, ROOT)
 import yolo_tf_amd as y                                    # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
-EVENT_EVERY = 10                 # steps between two event-bracketed launches of the dominant kernel
+INFINITY_CACHE_BYTES = 256 << 20
 PRIME_STEPS = 64                 # untimed steps before the W warm-up steps: pipelines and host caches reach steady state
-ROTATE = 4                       # distinct input sets, so that no step re-reads data the 256 MiB Infinity Cache still holds
+EXTRA_REGIONS = 6                # timed regions after the first, for the percentiles
 
 WORKLOADS = {
     'detect416': dict(kind='detect', size=416, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
@@ -52,12 +70,12 @@ WORKLOADS = {
                       name='YOLOv2 416x416 VOC-20 batch 1 decode+NMS (the reference\'s own CPU-runnable case), 845 boxes/img'),
     'detect608': dict(kind='detect', size=608, C=80, batch=64, thr=0.5, iou=0.5, max_boxes=10, dist={},
                       name='YOLOv3 608x608 COCO-80 decode+NMS, synthetic head tensors, 22743 boxes/img'),
-    'stress': dict(kind='detect', size=None, C=80, batch=16, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
+    'stress': dict(kind='detect', size=None, C=80, batch=128, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
                    name='NMS stress: 100x100 grid x 10 priors, ~1e5 candidates/img at score_thresh 0.001, 80 classes'),
     'loss416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101,
                     name='YOLOv3 416x416 training loss path: 100 GT boxes/img IoU ignore-mask + target assignment'),
     'train416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101, backward=True,
-                     name='YOLOv3 416x416 training loss path, forward + backward to the head tensors (autograd)'),
+                     name='YOLOv3 416x416 training loss path, forward + backward to the head tensors'),
 }
 
 
@@ -75,35 +93,65 @@ def build_head(w):
     return y.synth.v3_grids(w['size']), priors, (32.0, 32.0, 16.0), (32.0, 16.0, 8.0)
 
 
-def cpu_baseline(w, grids, priors, box_mult, gt_rate, budget_s=12.0):
-    """Times the C restatement on the host cores for a bounded sample."""
-    from oracle import c_oracle as co
-    threads = max(1, min(16, int(os.environ.get('OMP_NUM_THREADS', '0')) or (os.cpu_count() or 1)))
-    cfg = co.make_config(grids, priors, box_mult, gt_rate, w['C'])
-    P = len(priors[0])
-    Bs = 2 * threads
-    heads = y.synth.make_heads(4242, Bs, grids, P, w['C'], **w.get('dist', {}))
-    if w['kind'] == 'detect':
-        fn = lambda: co.detect(cfg, heads, w['thr'], w['iou'], w['max_boxes'], threads=threads, unpack=False)
-    else:
-        gt = y.synth.make_ground_truth(4243, Bs, w['G'], w['pad'], w['size'], w['C'])
-        fn = lambda: co.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.5, True, threads=threads)
+# ----------------------------------------------------------------------------- CPU baselines
+def _time_for(fn, budget_s, max_reps=10000):
     fn()                                                    # warm-up (page-in, thread pool)
     reps, t0 = 0, time.perf_counter()
     while True:
         fn(); reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 10000:
-            break
-    return dict(value=round(Bs * reps / el, 2), unit='images/sec', cores=threads, kind='port',
-                sample='%d synthetic images x %d passes (%.1f s) of the same workload, C restatement of the '
-                       'reference op sequence (oracle/yolo_head_oracle.c), OpenMP over images' % (Bs, reps, el))
+        if el >= budget_s or reps >= max_reps:
+            return reps, el
 
 
+def cpu_baseline(w, grids, priors, box_mult, gt_rate):
+    """The CPU restatements of the reference's op sequence on this host, bounded samples."""
+    from oracle import c_oracle as co, yolo_head_oracle as O
+    threads = max(1, min(16, int(os.environ.get('OMP_NUM_THREADS', '0')) or (os.cpu_count() or 1)))
+    cfg = co.make_config(grids, priors, box_mult, gt_rate, w['C'])
+    P = len(priors[0])
+    big = w['size'] is None                                  # 1e5 boxes per image: fewer images per pass
+
+    def sample(n_img, nthreads, budget):
+        heads = y.synth.make_heads(4242, n_img, grids, P, w['C'], **w.get('dist', {}))
+        if w['kind'] == 'detect':
+            fn = lambda: co.detect(cfg, heads, w['thr'], w['iou'], w['max_boxes'], threads=nthreads, unpack=False)
+        else:
+            gt = y.synth.make_ground_truth(4243, n_img, w['G'], w['pad'], w['size'], w['C'])
+            fn = lambda: co.loss(cfg, heads, gt, (1., 1., 5., 1.), 0.5, True, threads=nthreads)
+        reps, el = _time_for(fn, budget)
+        return n_img * reps / el, '%d synthetic images x %d passes (%.1f s)' % (n_img, reps, el), heads
+
+    rate, what, _ = sample(threads if big else 2 * threads, threads, 10.0)
+    res = dict(value=round(rate, 2), unit='images/sec', cores=threads, kind='port',
+               sample=what + ' of the same workload, C restatement of the reference op sequence '
+                             '(oracle/yolo_head_oracle.c), OpenMP over images')
+    rate1, what1, heads1 = sample(1 if big else 4, 1, 5.0)
+    res['single_thread'] = dict(value=round(rate1, 2), unit='images/sec', cores=1, kind='port', sample=what1 + ', the same C code on one thread')
+    # NumPy restatement (oracle/yolo_head_oracle.py), one image per pass
+    h0 = [h[0] for h in heads1]
+    if w['kind'] == 'detect':
+        fn = lambda: O.detect(h0, priors, box_mult, w['C'], w['thr'], w['max_boxes'], w['iou'])
+    elif w.get('version') == 2:
+        gt = y.synth.make_ground_truth(4243, 1, w['G'], w['pad'], w['size'], w['C'])
+        fn = lambda: O.loss_v2_image(h0[0], gt[0], priors[0], w['C'])
+    else:
+        gt = y.synth.make_ground_truth(4243, 1, w['G'], w['pad'], w['size'], w['C'])
+        fn = lambda: O.loss_v3_image(h0, gt[0], priors, w['C'])
+    try:
+        reps, el = _time_for(fn, 4.0)
+        res['numpy'] = dict(value=round(reps / el, 2), unit='images/sec', cores=1, kind='port',
+                            sample='1 synthetic image x %d passes (%.1f s), NumPy restatement op for op '
+                                   '(oracle/yolo_head_oracle.py)' % (reps, el))
+    except Exception as e:                                   # the baseline must not take the benchmark down
+        res['numpy'] = dict(value=None, error=repr(e))
+    return res
+
+
+# ----------------------------------------------------------------------------- helpers
 def measured_read_bandwidth(sets, dev, reps=20):
     """GB/s a read-only kernel reaches on these very buffers (yh_probe_read, HIP events): the
     achievable figure next to the nominal peak."""
-    import ctypes
     lib = y._abi.load()
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     bufs = [h for hs in sets for h in hs if h.numel() * 4 >= (32 << 20)] or [max((h for hs in sets for h in hs), key=lambda t: t.numel())]
@@ -121,23 +169,108 @@ def measured_read_bandwidth(sets, dev, reps=20):
     return nbytes / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
-def detect_kernel_name(workload):
-    """The dominant kernel of a detect workload, as csrc/yh_abi.hip::plan_stream picks it."""
-    if workload == 'stress':                                  # capacity beyond the single-launch select stage
-        return 'k_stream<detect> (workgroup tiles: decode + score filter + candidate compaction'
-    if os.environ.get('YH_DETECT_KERNEL', '1') == '1':
-        return 'k_detect_rows (objectness column, then the surviving rows: decode + score filter + candidate compaction'
-    return 'k_stream_wave (decode + score filter + candidate compaction'
+def detect_kernel(hd_cap, detect_kernel_knob):
+    """(short name, description) of the dominant kernel of a detect workload, as
+    csrc/yh_abi.hip::plan_stream picks it from the candidate capacity and the tuning."""
+    if hd_cap > 2048:                                        # capacity beyond the single-launch select stage
+        return 'k_stream', 'k_stream<detect> (workgroup tiles, reads the whole head: decode + score filter + candidate compaction)'
+    if detect_kernel_knob in (0, 1):
+        return 'k_detect_rows', ('k_detect_rows (objectness column, then the surviving rows: decode + score filter + '
+                                 'candidate compaction)')
+    return 'k_stream_wave', 'k_stream_wave (wave-private tiles, reads the whole head: decode + score filter + candidate compaction)'
 
 
-def load_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile, if one exists."""
-    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+def load_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` in `workload` from the committed PMC passes, or None."""
     try:
-        with open(path) as f:
-            return json.load(f).get(workload)
-    except (OSError, ValueError):
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            rec = json.load(f).get(workload, {}).get(kernel)
+    except (OSError, ValueError, AttributeError):
         return None
+    return rec if isinstance(rec, dict) else None
+
+
+def row_survival(sets, C, thr):
+    """Fraction of box rows whose objectness can still reach the score threshold
+    (sigmoid(obj) >= thr), over all input sets."""
+    if thr <= 0.0:
+        return 1.0
+    if thr >= 1.0:
+        return 0.0
+    logit = math.log(thr / (1.0 - thr))
+    n = k = 0
+    for hs in sets:
+        for h in hs:
+            obj = h.reshape(-1, C + 5)[:, C + 4]
+            k += int((obj >= logit).sum().item())
+            n += obj.numel()
+    return k / max(1, n)
+
+
+def rows_traffic_model(rows, survival, K):
+    """Bytes the objectness-first kernel must move per launch: one 128-byte line per row (the
+    objectness column) plus the surviving rows."""
+    return rows * 128.0 + rows * survival * K * 4.0
+
+
+def percentiles(xs):
+    a = np.asarray(xs, np.float64)
+    return dict(p10=round(float(np.percentile(a, 10)), 5), p50=round(float(np.percentile(a, 50)), 5),
+                p90=round(float(np.percentile(a, 90)), 5), n=int(a.size))
+
+
+def rotation_for(touched_bytes_per_set, floor=4, cap=24):
+    """Distinct input sets so that a line is re-read only after 3x the Infinity Cache of other
+    lines has been touched."""
+    return int(max(floor, min(cap, math.ceil(3.0 * INFINITY_CACHE_BYTES / max(1.0, touched_bytes_per_set)))))
+
+
+def solo_kernel_ms(hd, w, sets, dev, per_run, runs=5):
+    """Average duration of one launch of the dominant kernel with launches back to back on one
+    stream (each launch also carries the previous batch's select stage when that rides along):
+    HIP event pairs around `runs` runs of `per_run` launches; all runs returned."""
+    solo = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes'], tag='solo')
+    n = len(sets)
+    for i in range(max(10, n)):
+        solo.submit(sets[i % n])
+    out = []
+    for _ in range(runs):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(per_run):
+            solo.submit(sets[i % n])
+        b.record()
+        torch.cuda.synchronize(dev)
+        out.append(a.elapsed_time(b) / per_run)
+    last = solo.flush()
+    return out, last
+
+
+def survival_sweep(w, grids, priors, box_mult, gt_rate, dev, B, rows_per_launch, K):
+    """The objectness-first kernel against the share of rows that survive its prefilter:
+    objectness ~ N(mu, 2) with mu chosen for about 2 / 16 / 50 / 100 % at threshold 0.5, class
+    logits too low for any candidate (so the candidate capacity plays no part).  Microseconds
+    per launch (one stream, back to back) and the fraction of the HBM peak the bytes that must
+    move (rows_traffic_model) reach."""
+    out = []
+    for mu in (-4.0, -2.0, 0.0, 9.0):
+        surv_nominal = 0.5 * (1.0 + math.erf(mu / 2.0 / math.sqrt(2.0)))
+        touched = rows_traffic_model(rows_per_launch, surv_nominal, K)
+        n_sets = rotation_for(touched, floor=3, cap=10)
+        sets = [y.synth.torch_heads(dev, 500 + i, B, grids, len(priors[0]), w['C'], obj_mean=mu, hot_mean=-6.0)
+                for i in range(n_sets)]
+        surv = row_survival(sets[:1], w['C'], w['thr'])
+        hd = y.DetectionHead(w['C'], priors, box_mult, gt_rate)
+        runs, last = solo_kernel_ms(hd, w, sets, dev, per_run=60, runs=3)
+        ms = float(np.median(runs))
+        model = rows_traffic_model(rows_per_launch, surv, K)
+        out.append(dict(obj_mean=mu, row_survival=round(surv, 4), kernel_us=round(ms * 1e3, 2),
+                        traffic_model_bytes=int(model), model_gbs=round(model / (ms * 1e-3) / 1e9, 1),
+                        frac=round(model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), input_sets=n_sets,
+                        overflow=bool(last.overflowed())))
+        del sets, hd
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -153,37 +286,61 @@ def main():
     ap.add_argument('--streams', type=int, default=None,
                     help='detect workloads, --in-flight 2: pipelines on streams of their own, fed in turn (the '
                          'latency-bound tail of one launch overlaps the bandwidth-bound start of the next); '
-                         '1 = one stream, launches back to back; default 3 (measured 17.2 us per step against '
-                         '17.7 with two and 25 with one on the default workload)')
+                         '1 = one stream, launches back to back; default 3')
+    ap.add_argument('--detect-kernel', type=int, default=0, choices=(0, 1, 2),
+                    help='yh_set_tuning.detect_kernel: 0/1 = objectness-first rows kernel, 2 = streaming kernel')
+    ap.add_argument('--force-allreduce', action='store_true',
+                    help='loss workloads with one rank: open a one-rank process group (RCCL) and all-reduce the loss '
+                         'pair anyway, so that the collective runs on a single GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the survival sweep of the detect416 line')
+    ap.add_argument('--regions', type=int, default=EXTRA_REGIONS, help='timed regions after the first (percentiles)')
     args = ap.parse_args()
 
     # YH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    rank, world, local_rank = y.parallel.init_from_env(os.environ.get('YH_DIST_BACKEND'))
+    rank, world, local_rank = y.parallel.init_from_env(os.environ.get('YH_DIST_BACKEND'), even_alone=args.force_allreduce)
     if world != max(1, args.gpus):
         raise SystemExit('--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the path has no CPU fallback')
     dev = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    if args.detect_kernel:
+        y._abi.set_tuning(detect_kernel=args.detect_kernel)
 
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['batch']
     grids, priors, box_mult, gt_rate = build_head(w)
     P, C = len(priors[0]), w['C']
+    K = C + 5
     hd = y.DetectionHead(C, priors, box_mult, gt_rate)
     N = sum(h * ww * P for h, ww in grids)
-    bytes_img = N * (C + 5) * 4
-
-    sets = [y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(ROTATE)]
+    bytes_img = N * K * 4
+    rows_per_launch = B * N
     steps, warmup = args.steps, args.warmup
-    # HIP events around the dominant kernel on a sample of the timed steps: an event record costs a
-    # few microseconds of stream time, comparable to the tail of the pipeline, so not on every step
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for i in range(0, steps, EVENT_EVERY)}
-    for a, b in ev.values():                                # force creation of the hipEvent_t handles
-        a.record(); b.record()
 
+    # ---- inputs: enough distinct sets that a step never re-reads lines the Infinity Cache still holds,
+    # sized by the bytes a step TOUCHES (the objectness-first kernel and the loss touch a fraction of a set)
+    if w['kind'] == 'detect':
+        probe = y.synth.torch_heads(dev, 1000 * rank, B, grids, P, C, **w.get('dist', {}))
+        surv0 = row_survival([probe], C, w['thr'])
+        hd.detect(probe, w['thr'], w['iou'], w['max_boxes']).resolved()     # settles the candidate capacity (untimed)
+        kname, kdesc = detect_kernel(hd.default_max_candidates(N), args.detect_kernel)
+        touched = rows_traffic_model(rows_per_launch, surv0, K) if kname == 'k_detect_rows' else float(B * bytes_img)
+    else:
+        probe, surv0 = None, None
+        kname, kdesc = 'k_loss_main', 'k_loss_main (ignore-mask IoU loop + assignment + loss sums; reads the objectness column and the assigned rows)'
+        touched = rows_per_launch * 128.0 * (3.0 if w.get('backward') else 1.0)
+    rotate = rotation_for(touched, cap=24 if B * bytes_img < (1 << 30) else 4)
+    sets = [probe if (i == 0 and probe is not None) else
+            y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(rotate)]
+    rotation_note = ('%d distinct input sets of %.0f MB, %.0f MB of lines touched per step: %.1fx the 256 MiB Infinity '
+                     'Cache between two reads of a line' % (rotate, B * bytes_img / 1e6, touched / 1e6,
+                                                            rotate * touched / INFINITY_CACHE_BYTES))
+
+    extra = {}
+    pipe = None
+    nstreams = 1
     if w['kind'] == 'detect':
         # Software pipeline over the sequence of batches, as a serving loop would run the path: a
         # step streams batch i and, inside the same launch, selects batch i-1 (yh_detect_pipelined).
@@ -191,58 +348,31 @@ def main():
         lanes = 2 if args.in_flight > 1 else 1
         outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
         nstreams = max(1, args.streams or w.get('streams', 3)) if lanes > 1 else 1
-        pipe = None
         if lanes > 1:
             pipe = (y.DetectLanes(hd, w['thr'], w['iou'], w['max_boxes'], lanes=nstreams, device=dev) if nstreams > 1
                     else y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes']))
 
-        def step(i, events=None):
-            if pipe is not None and nstreams > 1:
-                return pipe.submit(sets[i % ROTATE])          # the inputs are resident: nothing to wait for
+        def step(i):
             if pipe is not None:
-                return pipe.submit(sets[i % ROTATE], stream_events=events)
-            return hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs,
-                             stream_events=events)
-        extra = {'batches_in_flight': lanes * nstreams, 'streams': nstreams}
+                return pipe.submit(sets[i % rotate])          # the inputs are resident: nothing to wait for
+            return hd.detect(sets[i % rotate], w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
+        extra.update(batches_in_flight=lanes * nstreams, streams=nstreams)
     else:
         gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
-               for i in range(ROTATE)]
+               for i in range(rotate)]
+        reducer = y.parallel.LossReducer(dev, always_reduce=args.force_allreduce)   # persistent buffers: no allocation per step
+        if args.force_allreduce:
+            extra['allreduce'] = 'forced: %d-rank %s process group' % (world, dist.get_backend())
+        reuse = {}                                           # the loss outputs are written in place step after step
 
-        if w.get('backward'):
-            for hs in sets:
-                for h in hs:
-                    h.requires_grad_(True)
-
-        def step_autograd(i):
-            hs = sets[i % ROTATE]
-            for h in hs:
-                h.grad = None
-            total, _ = hd.loss_with_grad(hs, gts[i % ROTATE], 1., 1., 5., 1., 0.5, True)
-            (0.5 * total.reshape(()) / y.parallel.global_batch(B)).backward()
-            return y.parallel.global_mean_loss(total.detach(), B)
-
-        def step(i, events=None):
+        def step(i):
             if w.get('backward'):
                 # forward + backward in one library call: d(.5 * mean loss) / d(head) for every head
-                out, _grads = hd.loss_and_grad(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True,
+                out, _grads = hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True,
                                                grad_scale=0.5 / y.parallel.global_batch(B))
-                return y.parallel.global_mean_loss(out['sum'], B, out['mean'])
-            out = reuse['out'] = hd.loss(sets[i % ROTATE], gts[i % ROTATE], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
-            return y.parallel.global_mean_loss(out['sum'], B, out['mean'])   # the data-parallel scalar all-reduce
-        reuse = {}                                           # the loss outputs are written in place step after step
-        extra = {}
-        if w.get('backward'):
-            for i in range(5):
-                step_autograd(i)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for i in range(30):
-                step_autograd(i)
-            torch.cuda.synchronize(dev)
-            extra = {'through_autograd_ms_per_step': round((time.perf_counter() - t0) / 30 * 1e3, 5),
-                     'note': 'timed: loss_and_grad (yh_loss_with_grad: the gradient tensor is filled during the '
-                             'forward pass); through_autograd = the same step via torch.autograd '
-                             '(loss_with_grad + backward(): forward, then backward), host-bound by the engine'}
+            else:
+                out = reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
+            return reducer.global_mean(out)                  # the data-parallel scalar all-reduce
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -250,114 +380,84 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if w['kind'] == 'detect':
-        hd.detect(sets[0], w['thr'], w['iou'], w['max_boxes']).resolved()   # settles the candidate capacity (untimed)
-    last = None
-    # Pipelined detect: a step is exactly one launch of the dominant kernel, so one pair of events
-    # around the K back-to-back launches gives its average duration (launch gaps included) without
-    # putting event records between the launches.
-    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    one_launch_per_step = (w['kind'] == 'detect' and pipe is not None and
-                           hd.default_max_candidates(N) <= hd.SMALL_CAPACITY)   # the select stage rides along
-    # With several streams the pair sits on the first lane's stream and brackets that lane's launches:
-    # their average duration while the other lanes' launches overlap them.
-    multi = w['kind'] == 'detect' and pipe is not None and nstreams > 1
-    span_stream = pipe.streams[0] if multi else torch.cuda.current_stream(dev)
-    for e in span:                                          # creates the hipEvent_t handles now, not in the timed region
-        e.record(span_stream)
     gc.collect()
-    gc.disable()                                            # no collector pause inside the few-millisecond timed region
+    gc.disable()                                            # no collector pause inside the few-millisecond timed regions
     # Untimed priming, whatever W is: every lane's pipeline reaches its steady state (both workspaces
     # and output sets allocated, the prepared call of each slot built), and the host path is warm.
+    last = None
     for i in range(PRIME_STEPS):
         step(i)
     for i in range(warmup):
         last = step(i)
     barrier()
-    span_launches = sum(1 for i in range(steps) if (pipe._i + i) % nstreams == 0) if multi else steps
     t0 = time.perf_counter()
-    if one_launch_per_step:
-        span[0].record(span_stream)
     for i in range(steps):
-        if w['kind'] == 'detect' and not one_launch_per_step and not multi and i in ev:
-            last = step(i, ev[i])
-        else:
-            last = step(i)
-    if one_launch_per_step:
-        span[1].record(span_stream)
+        last = step(i)
     enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    region_ms = [1e3 * elapsed / steps]
+    for _ in range(max(0, args.regions)):                   # more regions of the same length, for the spread
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            last = step(i)
+        barrier()
+        region_ms.append(1e3 * (time.perf_counter() - t1) / steps)
     gc.enable()
 
-    if w['kind'] == 'detect' and lanes > 1:
-        # one batch at a time, for reference (untimed, after the timed region): every step waits for the one before it
-        n_serial = max(10, steps // 4)
-        ts = time.perf_counter()
-        for i in range(n_serial):
-            hd.detect(sets[i % ROTATE], w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
-        barrier()
-        extra['serial_ms_per_step'] = round(1e3 * (time.perf_counter() - ts) / n_serial, 5)
-
+    kern_runs = None
     if w['kind'] == 'detect':
         if pipe is not None:
-            last = pipe.flush()                             # the last batch's select stage (outside the timed region,
-                                                            # which selected the last warm-up batch instead)
+            last = pipe.flush()                             # the last batch's select stage (outside the timed regions)
             if isinstance(last, list):
                 last = last[-1]
         if last.overflowed():
             raise SystemExit('candidate capacity overflow in the benchmark configuration')
         extra['host_enqueue_ms_per_step'] = round(1e3 * enqueue / steps, 5)
-        if one_launch_per_step and multi:
-            # The launches of the timed region overlap each other across the streams; a kernel trace
-            # (rocprofv3 serialises dispatches) shows the kernel on its own.  Both are reported: the
-            # overlapped per-launch duration from the timed region, and the kernel's own duration from
-            # a short single-stream section right after it (same inputs, same rotation), which is the
-            # one `roofline` prices and the committed trace must agree with.
-            extra['kernel_ms_overlapped'] = round(span[0].elapsed_time(span[1]) / span_launches, 5)
-            solo = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes'], tag='solo')
-            for i in range(10):
-                solo.submit(sets[i % ROTATE])
-            # five runs of back-to-back launches, each under its own event pair; the median run counts (a
-            # run in which the host falls behind with enqueueing would time the host, not the kernel)
-            per_run, runs = max(40, min(200, steps // 5)), []
-            for _ in range(5):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for i in range(per_run):
-                    solo.submit(sets[i % ROTATE])
-                b.record()
-                torch.cuda.synchronize(dev)
-                runs.append(a.elapsed_time(b) / per_run)
-            solo.flush()
-            kern_ms, n_timed = float(np.median(runs)), 5 * per_run
-            extra['kernel_ms_runs'] = [round(r, 5) for r in runs]
-            timing = ('HIP event pairs around 5 runs of %d back-to-back launches on one stream right after the timed region '
-                      '(median run; the timed region\'s launches overlap across %d streams: kernel_ms_overlapped)'
-                      % (per_run, nstreams))
-        elif one_launch_per_step:
-            kern_ms, n_timed = span[0].elapsed_time(span[1]) / span_launches, span_launches
-            timing = 'one HIP event pair around the %d back-to-back launches of the timed region' % steps
-        elif multi:
-            # several launches per step and several streams: the dominant kernel on its own, from event
-            # pairs around every 10th launch of a single-stream section right after the timed region
-            solo = y.DetectPipeline(hd, w['thr'], w['iou'], w['max_boxes'], tag='solo')
-            for i in range(5):
-                solo.submit(sets[i % ROTATE])
-            for i in range(steps):
-                solo.submit(sets[i % ROTATE], stream_events=ev.get(i))
-            torch.cuda.synchronize(dev)
-            solo.flush()
-            kern_ms, n_timed = float(np.mean([a.elapsed_time(b) for a, b in ev.values()])), len(ev)
-            timing = ('HIP event pairs around every %dth launch of a single-stream section right after the timed region '
-                      '(whose steps overlap across %d streams)' % (EVENT_EVERY, nstreams))
-        else:
-            kern_ms, n_timed = float(np.mean([a.elapsed_time(b) for a, b in ev.values()])), len(ev)
-            timing = 'HIP event pairs around every %dth launch of the timed region' % EVENT_EVERY
         extra['detections_per_image_last_step'] = round(float(last.count.float().mean().item()), 2)
+        # one batch at a time (yh_detect, every call complete before the next), for reference
+        n_serial = max(10, min(200, steps // 4))
+        ts = time.perf_counter()
+        for i in range(n_serial):
+            hd.detect(sets[i % rotate], w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
+        barrier()
+        extra['serial_ms_per_step'] = round(1e3 * (time.perf_counter() - ts) / n_serial, 5)
+        if kname == 'k_stream':
+            # several launches per step: the dominant kernel under its own event pairs (yh_detect_timed)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+            for a, b in evs:                                  # a first record creates the hipEvent_t handles
+                a.record(); b.record()
+            for a, b in evs:
+                hd.detect(sets[0], w['thr'], w['iou'], w['max_boxes'], outputs=outputs, stream_events=(a, b))
+            evs = evs[2:]
+            for i, (a, b) in enumerate(evs):
+                hd.detect(sets[i % rotate], w['thr'], w['iou'], w['max_boxes'], outputs=outputs, stream_events=(a, b))
+            torch.cuda.synchronize(dev)
+            kern_runs = [a.elapsed_time(b) for a, b in evs]
+            timing = 'HIP event pairs around the kernel in %d yh_detect_timed calls after the timed regions' % len(evs)
+        else:
+            kern_runs, _ = solo_kernel_ms(hd, w, sets, dev, per_run=max(40, min(200, steps // 5)))
+            timing = ('HIP event pairs around 5 runs of back-to-back launches on one stream after the timed regions (median '
+                      'run; one launch = this kernel with the previous batch\'s select stage riding in its first workgroups)')
     else:
-        kern_ms = None
         extra['mean_loss_last_step'] = float(last.item())
+        # the loss kernel alone: event pairs around back-to-back yh_loss calls without the reducer
+        runs = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(100):
+                if w.get('backward'):
+                    hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, grad_scale=0.5 / B)
+                else:
+                    reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
+            b.record()
+            torch.cuda.synchronize(dev)
+            runs.append(a.elapsed_time(b) / 100)
+        kern_runs = runs
+        timing = ('HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run): the loss '
+                  'kernel plus its one-workgroup finalize launch, no all-reduce')
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -366,56 +466,61 @@ def main():
 
     if rank == 0:
         value = world * B * steps / elapsed
+        kern_ms = float(np.median(kern_runs))
+        config = dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=B * world,
+                      boxes_per_image=N, num_classes=C, bytes_per_image=bytes_img,
+                      parallelism='images sharded across %d GPU(s), no data-path collective' % world
+                      if w['kind'] == 'detect' else
+                      'images sharded across %d GPU(s), one scalar all-reduce (RCCL) per step' % world,
+                      input_rotation=rotation_note, **extra)
+        if surv0 is not None:
+            config['row_survival'] = round(row_survival(sets, C, w['thr']), 5)
         res = {
             'metric': 'images/sec (decode+IoU+NMS) YOLOv3-416 COCO-80 at 1/2/4/8 GPU; % HBM peak',
             'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': round(1e3 * elapsed / steps, 5), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=B * world,
-                           boxes_per_image=N, num_classes=C, bytes_per_image=bytes_img,
-                           parallelism='images sharded across %d GPU(s), no data-path collective' % world
-                           if w['kind'] == 'detect' else
-                           'images sharded across %d GPU(s), one scalar all-reduce (RCCL) per step' % world,
-                           input_rotation='%d distinct input sets (%.0f MB each) so the 256 MiB Infinity Cache cannot serve a step'
-                                          % (ROTATE, B * bytes_img / 1e6), **extra),
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': config,
+            'timing': dict(regions_ms_per_step=[round(r, 5) for r in region_ms], **percentiles(region_ms),
+                           note='region 0 is the one value / ms_per_step report; every region is %d steps between '
+                                'barriers' % steps),
         }
-        if kern_ms is not None:
-            overlapped = nstreams if multi else 1
-            ach = B * bytes_img / (kern_ms * 1e-3) / 1e9
-            res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                                   frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
-                                   kernel=detect_kernel_name(args.workload)
-                                          + ('; the previous batch\'s NMS stage rides in the same launch)' if one_launch_per_step else ')'),
-                                   kernel_ms=round(kern_ms, 5), kernel_launches_timed=n_timed, kernel_timing=timing,
-                                   algorithmic_bytes_per_launch=B * bytes_img,
-                                   launches_in_flight=overlapped,
-                                   whole_pipeline_frac=round(value / world * bytes_img / 1e9 / HBM_PEAK_GBS, 4))
-            if overlapped > 1:
-                res['roofline']['overlap_note'] = ('achieved / frac price the kernel on its own (kernel_ms, what a kernel trace shows); '
-                                                   'in the timed region %d streams keep %d launches in flight together, so a step '
-                                                   'takes less than kernel_ms: whole_pipeline_frac and traffic_gbs use the step time'
-                                                   % (overlapped, overlapped))
-            if res['roofline']['traffic']:
-                step_ms = 1e3 * elapsed / steps if one_launch_per_step else kern_ms
-                tr = res['roofline']['traffic'] / (step_ms * 1e-3) / 1e9
-                res['roofline']['traffic_gbs'] = round(tr, 1)
-                res['roofline']['traffic_frac'] = round(tr / HBM_PEAK_GBS, 4)
-            if detect_kernel_name(args.workload).startswith('k_detect_rows'):
-                res['roofline']['note'] = ('achieved prices the algorithmic bytes (the whole head, N*(C+5)*4 per image) per launch; '
-                                           'the objectness-first kernel reads one cache line per row plus the surviving rows '
-                                           '(see traffic), so achieved can exceed the HBM peak')
-        else:
-            ach = value / world * bytes_img / 1e9
-            res['roofline'] = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                                   frac=round(ach / HBM_PEAK_GBS, 4), traffic=load_traffic(args.workload),
-                                   kernel='whole loss step (k_loss_main + k_loss_finalize + the scalar mean), wall clock',
-                                   algorithmic_bytes_per_launch=B * bytes_img)
+        rec = load_traffic(args.workload, kname)
+        algo = float(B * bytes_img)
+        model = rows_traffic_model(rows_per_launch, config.get('row_survival', 1.0), K) if kname == 'k_detect_rows' else (
+            rows_per_launch * 128.0 if kname == 'k_loss_main' else algo)
+        traffic = float(rec['bytes_per_launch']) if rec else None
+        priced = traffic if traffic is not None else model
+        ach = priced / (kern_ms * 1e-3) / 1e9
+        res['roofline'] = dict(
+            bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+            traffic=int(traffic) if traffic is not None else None,
+            traffic_source=(rec.get('source') if rec else 'no committed PMC pass for this (workload, kernel): achieved / frac '
+                                                           'price traffic_model instead'),
+            traffic_model=int(model), kernel=kdesc, kernel_key=kname, kernel_ms=round(kern_ms, 5),
+            kernel_ms_runs=[round(r, 5) for r in kern_runs], kernel_timing=timing,
+            algorithmic_bytes_per_launch=int(algo), algorithmic_gbs=round(algo / (kern_ms * 1e-3) / 1e9, 1),
+            algorithmic_frac=round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            step_traffic_gbs=round(priced / (1e-3 * region_ms[0]) / 1e9, 1),
+            step_traffic_frac=round(priced / (1e-3 * region_ms[0]) / 1e9 / HBM_PEAK_GBS, 4),
+            whole_pipeline_algorithmic_frac=round(value / world * bytes_img / 1e9 / HBM_PEAK_GBS, 4),
+            note=('achieved / frac: bytes the kernel moves through HBM per launch (traffic) over its duration on its own; '
+                  'algorithmic_*: N*(C+5)*4 bytes per image over the same duration' +
+                  ('; the kernel reads a line per row plus the rows that survive the objectness prefilter (row_survival '
+                   '%.4f), so the algorithmic figure can exceed the peak and falls as more rows survive (survival_sweep); '
+                   'step_traffic_*: the same bytes over the step time of the timed region, where %d streams overlap launches'
+                   % (config.get('row_survival', 0.0), nstreams) if kname == 'k_detect_rows' else '')))
+        if surv0 is not None:
+            res['roofline']['row_survival'] = config['row_survival']
         res['roofline']['achievable_read_gbs'] = round(measured_read_bandwidth(sets, dev), 1)
-        res['roofline']['frac_of_achievable'] = round(res['roofline']['achieved'] / res['roofline']['achievable_read_gbs'], 4)
+        res['roofline']['frac_of_achievable'] = round(ach / res['roofline']['achievable_read_gbs'], 4)
+        if args.workload == 'detect416' and kname == 'k_detect_rows' and not args.no_sweep and world == 1:
+            del sets
+            torch.cuda.empty_cache()
+            res['survival_sweep'] = survival_sweep(w, grids, priors, box_mult, gt_rate, dev, B, rows_per_launch, K)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(w, grids, priors, box_mult, gt_rate)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -235,7 +235,11 @@ int yh_nms(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
  *   [0] = sum over the batch's images (the value a data-parallel caller
  *   all-reduces before dividing by the global batch), [1] = that sum divided
  *   by `batch` in fp32 (reduce_mean over this call's images, YOLOv3.py:311:
- *   the total_loss of a single-process caller). */
+ *   the total_loss of a single-process caller).
+ *   After the call the first 16 bytes of `workspace` hold two doubles: the sum
+ *   of the per-image losses before its rounding to fp32, and `batch`.  A
+ *   data-parallel caller all-reduces (sum) that pair in place and divides:
+ *   reduce_mean over the global batch without a staging buffer of its own. */
 int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pad, size_t *bytes);
 int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
             int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,

@@ -29,5 +29,23 @@ np.testing.assert_allclose(float(mean), float(mean_full), rtol=1e-6)
 gathered = [torch.zeros(()) for _ in range(world)]
 dist.all_gather(gathered, mean)
 assert float(gathered[0]) == float(gathered[1])             # identical on every rank
+# the step loop's form: the loss kernel's fp64 pair, all-reduced asynchronously in a ring of persistent buffers
+red = y.parallel.LossReducer(torch.device('cpu'), depth=4)
+pending = []
+for step in range(5):
+    sum64 = float(np.sum(per_local.astype(np.float64))) * (step + 1)
+    out = dict(sum=torch.tensor([sum64], dtype=torch.float32), mean=None, per_image=torch.zeros(b1 - b0),
+               reduce_pair=torch.tensor([sum64, b1 - b0], dtype=torch.float64))
+    pending.append(red.global_mean(out))
+want64 = float(np.sum(per_full.astype(np.float64))) / B
+try:                                                        # five steps through four buffers: the first one is gone
+    pending[0].item()
+    raise AssertionError('a stale PendingMean must raise')
+except RuntimeError:
+    pass
+for step, p in list(enumerate(pending))[1:]:
+    assert isinstance(p, y.parallel.PendingMean)
+    np.testing.assert_allclose(p.item(), want64 * (step + 1), rtol=1e-6)
+    assert p.tensor().dtype == torch.float32 and p.tensor().dim() == 0
 print('GLOO_OK rank %d mean %.6f' % (rank, float(mean)))
 dist.destroy_process_group()

@@ -1,0 +1,105 @@
+"""Property tests (hypothesis): random head geometries, thresholds and ground truth, the HIP path
+through the C ABI against the C oracle.  Bounded example counts and derandomised draws, so the GPU
+run is short and repeats itself."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import yolo_tf_amd as y
+from tests import cases
+from tests.test_gpu_parity import to_dev, assert_close, RTOL
+
+pytestmark = pytest.mark.gpu
+
+SETTINGS = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@st.composite
+def geometries(draw, max_classes=300):
+    S = draw(st.integers(1, 4))
+    P = draw(st.sampled_from([1, 2, 3, 5, 9, 16]))
+    C = draw(st.sampled_from([1, 2, 3, 20, 59, 64, 65, 80, 128, 129, max_classes]))
+    grids = [(draw(st.integers(1, 7)), draw(st.integers(1, 7))) for _ in range(S)]
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    priors = [rng.uniform(0.3, 4.0, size=(P, 2)).astype(np.float32) for _ in range(S)]
+    mult = tuple(float(draw(st.sampled_from([8.0, 16.0, 32.0]))) for _ in range(S))
+    rate = tuple(float(draw(st.sampled_from([8.0, 16.0, 32.0]))) for _ in range(S))
+    size = int(32 * max(max(g) for g in grids))
+    return cases.Case('prop', grids, priors, mult, rate, C, size, 3), seed
+
+
+@settings(max_examples=30, **SETTINGS)
+@given(geo=geometries(), B=st.integers(1, 3),
+       thr=st.sampled_from([0.0, 1e-3, 0.05, 0.3, 0.5, 0.9, 1.0]), iou=st.sampled_from([0.0, 0.3, 0.5, 1.0]),
+       mb=st.sampled_from([1, 3, 10, 100]), obj_mean=st.sampled_from([-3.0, 0.0, 3.0]))
+def test_detect_stages_against_the_oracle(gpu, c_oracle, geo, B, thr, iou, mb, obj_mean):
+    """decode 1e-5 against the oracle; score filter + NMS bit-exact on the GPU's own decoded
+    arrays; the fused call (from the head tensors) equal to the staged one, boxes included."""
+    case, seed = geo
+    heads = case.heads(seed % 9973, B, obj_mean=obj_mean, cold_mean=-2.0)
+    dheads = to_dev(heads, gpu)
+    hd = case.head_obj()
+    boxes, conf = hd.decode(dheads)
+    wb, wc = c_oracle.decode(case.oracle_cfg(c_oracle), heads)
+    assert_close(boxes.cpu().numpy(), wb, rtol=RTOL, atol=RTOL * case.size * 4, what='boxes')
+    assert_close(conf.cpu().numpy(), wc, rtol=RTOL, atol=1e-30, what='conf')
+    staged = hd.nms(boxes, conf, thr, iou, mb, want_class_candidates=True).resolved()
+    hb, hc = boxes.cpu().numpy(), conf.cpu().numpy()
+    want = c_oracle.nms(hb, hc, thr, iou, mb)
+    got = staged.per_image()
+    cases.same_detections(got, want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0].view(np.uint32), w[0].view(np.uint32))
+        assert np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32))
+    assert np.array_equal(staged.class_candidates.cpu().numpy(), (hc >= np.float32(thr)).sum(axis=1).astype(np.int32))
+    fused = hd.detect(dheads, thr, iou, mb, want_class_candidates=True).resolved()
+    cases.same_detections(fused.per_image(), got)
+    for f, g in zip(fused.per_image(), got):
+        assert np.array_equal(f[0], g[0]) and np.array_equal(f[1], g[1])
+    assert torch.equal(fused.class_candidates, staged.class_candidates)
+
+
+@st.composite
+def ground_truths(draw, case, B):
+    """[B, pad, 5] with duplicates, zero-area rows, centres outside the image and ragged counts."""
+    pad = draw(st.integers(2, 40))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    gt = np.full((B, pad, 5), -1.0, np.float32)
+    for b in range(B):
+        G = int(rng.integers(1, pad))                          # at least one row, at least one pad row
+        yx = rng.uniform(-0.1 * case.size, 1.1 * case.size, size=(G, 2))
+        hw = np.exp(rng.uniform(np.log(2.0), np.log(case.size), size=(G, 2)))
+        kind = rng.integers(0, 6, size=G)
+        hw[kind == 0] = 0.0                                    # zero-area box
+        for g in np.nonzero(kind == 1)[0]:                     # duplicate of an earlier row
+            j = int(rng.integers(0, g + 1))
+            yx[g], hw[g] = yx[j], hw[j]
+        gt[b, :G, 0:2] = np.maximum(yx, 0.0)                   # a negative yc would end the argmin slice early
+        gt[b, :G, 2:4] = hw
+        gt[b, :G, 4] = rng.integers(0, case.C + 2, size=G)     # labels beyond C: all-zero one-hot row
+    return gt
+
+
+@settings(max_examples=25, **SETTINGS)
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 3), version=st.sampled_from([2, 3]),
+       thr=st.sampled_from([0.0, 0.3, 0.5, 0.6, 1.0]))
+def test_loss_against_the_oracle(gpu, c_oracle, data, geo, B, version, thr):
+    """Ignore-mask IoU maxima bit-identical, loss parts and per-image losses 1e-5, with and without
+    the division-free mask, v2- and v3-style normalisation."""
+    case, seed = geo
+    gt = data.draw(ground_truths(case, B))
+    heads = case.heads(seed % 7919, B, obj_mean=-1.0)
+    norm = version == 3
+    scales = (1.0, 0.5, 5.0, 2.0)
+    hd = case.head_obj()
+    dheads, dgt = to_dev(heads, gpu), torch.from_numpy(gt).to(gpu)
+    out = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=True)
+    per, parts, iou, _ = c_oracle.loss(case.oracle_cfg(c_oracle), heads, gt, scales, thr, norm, want_iou=True)
+    assert np.array_equal(out['iou_max'].cpu().numpy().view(np.uint32), iou.view(np.uint32))
+    assert_close(out['parts'].cpu().numpy(), parts, rtol=RTOL, atol=1e-6, what='loss parts')
+    assert_close(out['per_image'].cpu().numpy(), per, rtol=RTOL, atol=1e-6, what='per-image loss')
+    fast = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True)
+    assert np.array_equal(fast['parts'].cpu().numpy().view(np.uint32), out['parts'].cpu().numpy().view(np.uint32))

@@ -225,3 +225,24 @@ def test_gradient_restatement_against_torch_autograd(version):
         ref = t.grad.numpy()
         assert np.count_nonzero(ref) > 0
         assert np.allclose(g, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_sigmoid_and_cross_entropy_against_torch():
+    """A third witness for the recalled TensorFlow semantics that is importable here: torch's
+    sigmoid and binary_cross_entropy_with_logits (the same documented formula,
+    max(x, 0) - x * z + log(1 + exp(-|x|))) on CPU against the restatements, 1e-6.  It pins
+    nothing of TensorFlow's, it catches a misreading shared by the two restatements."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.normal(0, 4, size=4000), [-100., -30., -1e-8, 0., 1e-8, 30., 100.]]).astype(np.float32)
+    z = np.concatenate([rng.uniform(0, 1, size=2000), rng.integers(0, 2, size=2000), [0, 1, 0, 1, .5, 1, 0]]).astype(np.float32)
+    want_s = torch.sigmoid(torch.from_numpy(x).double()).numpy()
+    want_ce = F.binary_cross_entropy_with_logits(torch.from_numpy(x).double(), torch.from_numpy(z).double(),
+                                                 reduction='none').numpy()
+    np.testing.assert_allclose(O.sigmoid(x), want_s, rtol=1e-6, atol=1e-30)
+    # fp32 evaluation of max(x, 0) - x * z + log1p(exp(-|x|)): each term rounds at the scale of |x|
+    bound = 1e-6 * np.abs(want_ce) + 2.4e-7 * (1.0 + np.abs(x.astype(np.float64)))
+    assert np.all(np.abs(O.sigmoid_ce(x, z).astype(np.float64) - want_ce) <= bound)
+    f32 = F.binary_cross_entropy_with_logits(torch.from_numpy(x), torch.from_numpy(z), reduction='none').numpy()
+    assert np.all(np.abs(O.sigmoid_ce(x, z).astype(np.float64) - f32) <= 2 * bound)

@@ -280,7 +280,6 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
     p.S = cfg->num_scales; p.B = B; p.C = cfg->num_classes; p.P = cfg->num_priors;
     p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg);
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
-    p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
     p.scan_col_step = 1024 % p.K;
     uint32_t row_base = 0;
     for (int s = 0; s < p.S; ++s) {
@@ -665,7 +664,6 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     std::memset(&p, 0, sizeof(p));
     p.S = 1; p.B = batch; p.C = num_classes; p.P = 1; p.K = num_classes; p.N = (int32_t)boxes_per_img;
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
-    p.magic_c = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.C) + 1u;
     p.scan_col_step = 1024 % p.K;
     p.thr = score_threshold;
     p.cand_cap = max_candidates;
@@ -705,7 +703,7 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
     if (p.pos_blocks < 1) p.pos_blocks = 1;
 }
 
-struct LossWs { float *neg, *pos; int32_t *gcount; size_t bytes; };
+struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; size_t bytes; };
 
 static LossWs carve_loss(void *base, const yh::LossParams &p)
 {
@@ -713,9 +711,11 @@ static LossWs carve_loss(void *base, const yh::LossParams &p)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     char *c = static_cast<char *>(base);
+    const size_t o_pair = take(2 * sizeof(double));            // offset 0: documented in yolohead.h
     const size_t o_neg = take((size_t)p.B * p.blocks_per_img * 4);
     const size_t o_pos = take((size_t)p.B * p.pos_blocks * 3 * 4);
     const size_t o_g = take((size_t)p.B * 4);
+    w.pair = reinterpret_cast<double *>(c + o_pair);
     w.neg = reinterpret_cast<float *>(c + o_neg);
     w.pos = reinterpret_cast<float *>(c + o_pos);
     w.gcount = reinterpret_cast<int32_t *>(c + o_g);
@@ -793,7 +793,7 @@ static int loss_forward(const yh_head_config *cfg, const float *const *heads, co
     p.ignore_thr = ignore_threshold;
     p.normalize = normalize_by_num_gt ? 1 : 0;
     p.gt = ground_truth;
-    p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount;
+    p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount; p.reduce_pair = w.pair;
     p.loss_per_image = loss_per_image; p.loss_parts = loss_parts; p.iou_max = iou_max; p.loss_sum = loss_sum;
     p.noobj_mask = noobj_mask;
     const hipError_t e = yh::launch_loss(p, static_cast<hipStream_t>(stream));

@@ -71,8 +71,7 @@ struct StreamScale {
 
 struct StreamParams {
     int32_t S, B, C, P, K, N;
-    uint32_t magic_k;       // floor(2^32 / K) + 1
-    uint32_t magic_c;       // floor(2^32 / C) + 1
+    uint32_t magic_k;       // floor(2^32 / K) + 1: row of a flat index by multiply-high (K >= 2)
     int32_t scan_col_step;  // (floats a workgroup scans per step: 4 * 256) mod K
     int32_t tile_rows;      // rows per LDS tile: floor((tile floats - 3) / K)
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
@@ -183,6 +182,7 @@ struct LossParams {
     float *loss_parts;            // [B][4] or null
     float *iou_max;               // [B][N] or null
     float *loss_sum;              // [2]: sum, mean over the call's images
+    double *reduce_pair;          // [2] at the start of the workspace: fp64 sum of the per-image losses, image count
     uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
     const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
     LossScale sc[YH_MAX_SCALES];

@@ -515,11 +515,15 @@ __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum
         for (int k = 0; k < kPerGroup; ++k) s_sum[grp + k * kFinalizeGroups] = local[k];
     }
     __syncthreads();
-    if (tid == 0 && p.loss_sum) {
+    if (tid == 0) {
         double acc = 0.0;
         for (int g = 0; g < kFinalizeClasses; ++g) acc += s_sum[g];
-        p.loss_sum[0] = (float)acc;
-        p.loss_sum[1] = (float)acc / (float)p.B;              // reduce_mean over this call's images, in fp32
+        if (p.loss_sum) {
+            p.loss_sum[0] = (float)acc;
+            p.loss_sum[1] = (float)acc / (float)p.B;          // reduce_mean over this call's images, in fp32
+        }
+        p.reduce_pair[0] = acc;                                // what a data-parallel caller all-reduces in place
+        p.reduce_pair[1] = (double)p.B;
     }
 }
 

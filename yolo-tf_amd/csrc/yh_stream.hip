@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         const int valid = rows_t * K;
         auto exact = [&](int fi) {
             if ((uint32_t)fi >= (uint32_t)valid) return;      // the window's few floats around the tile
-            const int rr = (int)__umulhi((uint32_t)fi, p.magic_k), c = fi - rr * K;      // fi < 2^13
+            // fi < 2^13; K = 1 (a one-class confidence matrix) has no 32-bit reciprocal
+            const int rr = K == 1 ? fi : (int)__umulhi((uint32_t)fi, p.magic_k), c = fi - rr * K;
             if (c >= C) return;
             const float *rp = tile + rr * K;
             const float x = rp[c];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         };
         const uint32_t behind = (uint32_t)(K - C);            // columns C .. K-1 hold no class logit
         const int fi_first = 4 * tid - sh;                    // -3 .. -1: before the tile
-        int col0 = fi_first >= 0 ? fi_first - (int)__umulhi((uint32_t)fi_first, p.magic_k) * K : fi_first + K;
+        int col0 = fi_first >= 0 ? (K == 1 ? 0 : fi_first - (int)__umulhi((uint32_t)fi_first, p.magic_k) * K) : fi_first + K;
         for (int w = tid; w < wslots; w += kThreads) {
             const float4 v = reinterpret_cast<const float4 *>(st.tile)[w];
             const uint32_t t0 = (uint32_t)(col0 - C);

@@ -344,9 +344,13 @@ class DetectionHead:
                 _abi.check(lib.yh_loss_forward(*common, mask.data_ptr() if want_mask else None, self._stream(dev)))
         if out is not None:
             out['grads'] = grads
+            if out['reduce_pair'].data_ptr() != ws.data_ptr():
+                out['reduce_pair'] = ws[:16].view(torch.float64)
             return out
+        # reduce_pair: the workspace's leading fp64 pair (sum of the per-image losses, image count), valid
+        # until the next loss call on this head and shape: what parallel.LossReducer all-reduces
         return dict(per_image=per, sum=total[:1], mean=total[1:], parts=parts, iou_max=iou, noobj_mask=mask,
-                    _total=total, grads=grads)
+                    _total=total, grads=grads, reduce_pair=ws[:16].view(torch.float64))
 
     def loss_backward(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
                       normalize_by_num_gt, noobj_mask, grad_per_image):

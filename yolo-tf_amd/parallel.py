@@ -18,14 +18,17 @@ def shard_range(total, rank, world_size):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, even_alone=False):
     """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK /
-    MASTER_ADDR / MASTER_PORT when WORLD_SIZE > 1.  Returns (rank, world,
-    local_rank).  backend defaults to nccl (RCCL) when a GPU is present."""
+    MASTER_ADDR / MASTER_PORT when WORLD_SIZE > 1 (even_alone: also a one-rank
+    group, so that the collective code runs on a single GPU).  Returns (rank,
+    world, local_rank).  backend defaults to nccl (RCCL) when a GPU is present."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if even_alone and world == 1:
+        os.environ.setdefault('MASTER_PORT', '29741')
+    if (world > 1 or even_alone) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -42,18 +45,102 @@ def global_batch(local_batch):
     return int(local_batch)
 
 
-def global_mean_loss(local_sum, local_batch, local_mean=None):
-    """reduce_mean over the global batch.  local_sum: tensor [1] (or 0-dim)
-    holding this rank's sum of per-image losses; local_mean: the same sum
-    already divided by local_batch in fp32 (the loss kernel writes both), used
-    as it is when there is one rank.  Returns a 0-dim float32 tensor on
-    local_sum's device, identical on every rank."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        buf = torch.empty(2, dtype=torch.float64, device=local_sum.device)
-        buf[0] = local_sum.reshape(())
-        buf[1] = float(local_batch)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        return (buf[0] / buf[1]).to(torch.float32)
-    if local_mean is not None:
-        return local_mean.reshape(())                           # one rank: the fp32 mean, taken in the loss kernel
-    return local_sum.reshape(()) / float(local_batch)          # one rank: the fp32 mean the reference computes
+def global_mean_loss(local_sum, local_batch=None, local_mean=None):
+    """reduce_mean over the global batch.  local_sum: the dict DetectionHead.loss() returned, or
+    a tensor [1] (or 0-dim) holding this rank's sum of per-image losses together with
+    local_batch; local_mean: the same sum already divided by local_batch in fp32 (the loss
+    kernel writes both), used as it is when there is one rank.  Returns a 0-dim float32 tensor
+    on the sum's device, identical on every rank (one all-reduce of two fp64 values through a
+    per-device LossReducer)."""
+    dev = (local_sum['sum'] if isinstance(local_sum, dict) else local_sum).device
+    reducer = _reducers.get(dev)
+    if reducer is None:
+        reducer = _reducers[dev] = LossReducer(dev)
+    res = reducer.global_mean(local_sum, local_batch, local_mean)
+    return res.tensor() if isinstance(res, PendingMean) else res
+
+
+_reducers = {}
+
+
+class PendingMean:
+    """The global mean loss of one step while its all-reduce may still be in flight: tensor() /
+    item() / float() wait for it (a stream-level wait under RCCL, no host synchronisation
+    before item()).  It lives in one of the reducer's `depth` persistent buffers: read it
+    before `depth` further steps have been reduced, later reads raise."""
+
+    def __init__(self, reducer, slot, generation, work):
+        self._reducer, self._slot, self._generation, self._work = reducer, slot, generation, work
+        self._done = False
+
+    def tensor(self):
+        r, k = self._reducer, self._slot
+        if r._generation[k] != self._generation:
+            raise RuntimeError('this step\'s mean loss was not read within %d steps: its buffer has been reused' % len(r._ring))
+        if not self._done:
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
+            r._out[k].copy_(r._ring[k][0] / r._ring[k][1])   # fp64 quotient, rounded to fp32 once
+            self._done = True
+        return r._out[k]
+
+    def item(self):
+        return float(self.tensor().item())
+
+    __float__ = item
+
+
+class LossReducer:
+    """reduce_mean over the global batch (YOLOv3.py:311) for a step loop, without per-step
+    allocations or host-to-device scalars: the loss kernel leaves the fp64 pair (sum of the
+    per-image losses, image count) at the head of its workspace (DetectionHead.loss()
+    ['reduce_pair']); that pair is copied into one of `depth` persistent buffers and
+    all-reduced there asynchronously, so the next step's kernels may overwrite the workspace
+    while the collective is in flight.  With one rank nothing is exchanged and the kernel's
+    own fp32 mean is returned."""
+
+    def __init__(self, device, depth=4, always_reduce=False):
+        self.always_reduce = always_reduce                   # all-reduce even in a one-rank process group
+        self._ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(depth)]
+        self._out = [torch.zeros((), dtype=torch.float32, device=device) for _ in range(depth)]
+        self._work = [None] * depth
+        self._generation = [0] * depth
+        self._i = 0
+
+    def global_mean(self, out_or_sum, local_batch=None, local_mean=None):
+        """out_or_sum: the dict DetectionHead.loss() returned (preferred: carries reduce_pair), or
+        the [1] tensor of this rank's loss sum together with local_batch (and local_mean).
+        Returns a 0-dim float32 tensor with one rank, a PendingMean otherwise."""
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.always_reduce)
+        pair = out_or_sum.get('reduce_pair') if isinstance(out_or_sum, dict) else None
+        if isinstance(out_or_sum, dict):
+            local_mean = out_or_sum['mean'] if local_mean is None else local_mean
+            local_sum = out_or_sum['sum']
+            local_batch = int(out_or_sum['per_image'].shape[0]) if local_batch is None else local_batch
+        else:
+            local_sum = out_or_sum
+        if not multi:
+            if local_mean is not None:
+                return local_mean.reshape(())
+            return local_sum.reshape(()) / float(local_batch)
+        k = self._i % len(self._ring)
+        self._i += 1
+        buf = self._ring[k]
+        if self._work[k] is not None:
+            self._work[k].wait()                             # the buffer's previous collective, `depth` steps ago
+        if pair is not None:
+            buf.copy_(pair)
+        else:
+            buf[0:1].copy_(local_sum.reshape(1))
+            buf[1].fill_(float(local_batch))
+        # asynchronous under RCCL, where waiting is a stream-level dependency; the CPU-side backends (gloo:
+        # tests and rehearsals) complete the collective before returning
+        if dist.get_backend() == 'nccl':
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            work = None
+        self._work[k] = work
+        self._generation[k] += 1
+        return PendingMean(self, k, self._generation[k], work)

@@ -122,7 +122,7 @@ class YOLOv2:
         out = self.head.loss([head], ground_truth, self.coord_sacle, self.noobj_scale, self.obj_scale,
                              self.class_scale, ignore_threshold=0.6, normalize_by_num_gt=False,
                              want_parts=want_parts)
-        total = parallel.global_mean_loss(out['sum'], head.shape[0], out['mean'])
+        total = parallel.global_mean_loss(out)
         return (total, out) if want_parts else total
 
     def _train_step(self, head, ground_truth, lr):
@@ -139,7 +139,7 @@ class YOLOv2:
         step = getattr(self.head_provider, 'step', None)
         if step is not None:
             step(lr)
-        return parallel.global_mean_loss(out['sum'], local_b, out['mean'])
+        return parallel.global_mean_loss(out)
 
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)

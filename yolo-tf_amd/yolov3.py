@@ -145,7 +145,7 @@ class YOLOv3:
         out = self.head.loss(heads, ground_truth, self.coord_sacle, self.noobj_scale, self.obj_scale,
                              self.class_scale, ignore_threshold=0.5, normalize_by_num_gt=True,
                              want_parts=want_parts)
-        total = parallel.global_mean_loss(out['sum'], heads[0].shape[0], out['mean'])
+        total = parallel.global_mean_loss(out)
         return (total, out) if want_parts else total
 
     def _train_step(self, heads, ground_truth, lr, loss_factor):
@@ -165,7 +165,7 @@ class YOLOv3:
         step = getattr(self.head_provider, 'step', None)
         if step is not None:
             step(lr)
-        return parallel.global_mean_loss(out['sum'], local_b, out['mean'])
+        return parallel.global_mean_loss(out)
 
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)

@@ -296,6 +296,9 @@ def main():
     ap.add_argument('--no-sweep', action='store_true', help='skip the survival sweep of the detect416 line')
     ap.add_argument('--regions', type=int, default=EXTRA_REGIONS, help='timed regions after the first (percentiles)')
     args = ap.parse_args()
+    if os.environ.get('YH_BENCH_WATCHDOG'):                   # diagnostics: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['YH_BENCH_WATCHDOG']), exit=True)
 
     # YH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     rank, world, local_rank = y.parallel.init_from_env(os.environ.get('YH_DIST_BACKEND'), even_alone=args.force_allreduce)
@@ -459,7 +462,7 @@ def main():
         timing = ('HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run): the loss '
                   'kernel plus its one-workgroup finalize launch, no all-reduce')
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

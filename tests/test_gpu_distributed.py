@@ -67,8 +67,9 @@ def test_bench_under_two_gloo_ranks(gpu, workload):
     because both ranks share this box's one GPU: sharding, barrier, max-over-ranks timing, the
     scalar all-reduce of the loss workload, one JSON line from rank 0."""
     env = dict(os.environ, YH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = {'detect416': '29747', 'loss416': '29757'}[workload]      # a port of its own: the last run's may still be closing
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29747', os.path.join(ROOT, 'bench.py'),
+                        '--master-addr', '127.0.0.1', '--master-port', port, os.path.join(ROOT, 'bench.py'),
                         '--gpus', '2', '--steps', '20', '--warmup', '2', '--regions', '1', '--workload', workload,
                         '--batch', '8', '--no-cpu-baseline'],
                        capture_output=True, text=True, timeout=400, env=env)

@@ -139,7 +139,9 @@ class LossReducer:
         if dist.get_backend() == 'nccl':
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            host = buf.cpu()                                 # gloo reduces host memory; its device path is not relied upon
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
             work = None
         self._work[k] = work
         self._generation[k] += 1

@@ -151,6 +151,28 @@ int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batc
               int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
               int32_t *status, void *stream);
 
+/* yh_detect without a workspace argument, for callers that cannot allocate or
+ * carry one: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  The workspace is
+ * a device array of YH_STATIC_SCRATCH_BYTES inside the library's code object
+ * (every GPU the library runs on holds its own copy until the process ends);
+ * the call allocates and frees nothing.  Arguments and results are those of
+ * yh_detect; a call whose yh_detect_workspace_bytes exceeds the array fails
+ * with YH_ERR_LIMIT (e.g. it holds batch 64 of YOLOv3-608 at max_candidates
+ * 512).  All calls on one GPU share the array: two calls that overlap in time
+ * on one GPU (different streams or threads) race; calls on one stream, of any
+ * shapes in any order, are fine (the call clears the counters it needs at
+ * zero itself).  The device of `stream` must be the current device.  The
+ * first call on a device looks the array's address up (hipGetSymbolAddress):
+ * make it before a graph capture begins. */
+#define YH_STATIC_SCRATCH_BYTES (8u << 20)
+int yh_detect_static(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                     float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                     int32_t max_candidates,
+                     int32_t *out_count, float *out_scores, float *out_boxes,
+                     int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                     int32_t *status, void *stream);
+
 /* yh_detect with two caller-created hipEvent_t (as void*, either may be NULL)
  * recorded on `stream` immediately before and after the streaming kernel
  * (decode + score filter + compaction), so that a benchmark can time the

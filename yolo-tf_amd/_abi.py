@@ -11,6 +11,7 @@ YH_MAX_CLASSES = 4096
 YH_MAX_BOXES_PER_IMAGE = 1 << 20
 YH_MAX_NMS_BOXES = 512
 YH_STATUS_CANDIDATE_OVERFLOW = 1
+YH_STATIC_SCRATCH_BYTES = 8 << 20
 
 YH_OK = 0
 YH_ERR_INVALID_ARG = -1
@@ -68,6 +69,7 @@ SIGNATURES = {
     'yh_detect_workspace_bytes': (ctypes.c_int, [_CFG, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)]),
     'yh_detect': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, ctypes.c_size_t,
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
+    'yh_detect_static': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'yh_detect_timed': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, ctypes.c_size_t,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'yh_detect_pipelined': (ctypes.c_int, [_CFG, _PP, _I, _F, _F, _I, _I, _P, _P, ctypes.c_size_t,

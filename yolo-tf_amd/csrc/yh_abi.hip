@@ -547,6 +547,63 @@ int yh_detect(const yh_head_config *cfg, const float *const *heads, int32_t batc
                        out_class_candidates, status, stream, nullptr, nullptr);
 }
 
+// ---- yh_detect_static: the workspace is a device array that lives in the library's code object.
+// In host code `g_static_scratch` is only a handle for hipGetSymbolAddress: the array's device
+// address differs per GPU and is looked up once per device, with that device current.
+static __device__ __align__(256) unsigned char g_static_scratch[YH_STATIC_SCRATCH_BYTES];
+
+static int static_scratch_of_current_device(void **out)
+{
+    constexpr int kDevices = 64;
+    static std::mutex mu;
+    static void *ptr_of[kDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= kDevices) return fail(YH_ERR_LIMIT, "device index %d outside [0, %d)", dev, kDevices);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+        if (e != hipSuccess || !ptr) return hip_fail(e, "hipGetSymbolAddress of the static scratch");
+        ptr_of[dev] = ptr;
+    }
+    *out = ptr_of[dev];
+    return YH_OK;
+}
+
+int yh_detect_static(const yh_head_config *cfg, const float *const *heads, int32_t batch,
+                     float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                     int32_t max_candidates,
+                     int32_t *out_count, float *out_scores, float *out_boxes,
+                     int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                     int32_t *status, void *stream)
+{
+    size_t need = 0;
+    int rc = yh_detect_workspace_bytes(cfg, batch, max_candidates, nms_max_boxes, &need);
+    if (rc != YH_OK) return rc;
+    if (need > (size_t)YH_STATIC_SCRATCH_BYTES)
+        return fail(YH_ERR_LIMIT, "this call needs %zu bytes of scratch, the static scratch holds %zu: lower batch or "
+                    "max_candidates, or pass a workspace to yh_detect", need, (size_t)YH_STATIC_SCRATCH_BYTES);
+    if (batch == 0)
+        return detect_impl(cfg, heads, batch, score_threshold, iou_threshold, nms_max_boxes, max_candidates,
+                           reinterpret_cast<void *>(256), need, out_count, out_scores, out_boxes, out_class, out_index,
+                           out_class_candidates, status, stream, nullptr, nullptr);
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    void *scratch = nullptr;
+    if ((rc = static_scratch_of_current_device(&scratch)) != YH_OK) return rc;
+    DetectPlan d;
+    rc = detect_prepare(d, cfg, heads, true, true, batch, score_threshold, iou_threshold, nms_max_boxes,
+                        max_candidates, scratch, (size_t)YH_STATIC_SCRATCH_BYTES, out_count, out_scores, out_boxes,
+                        out_class, out_index, out_class_candidates, status);
+    if (rc != YH_OK) return rc;
+    // The array keeps whatever the last call (of any shape) left where this call's counters lie.
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const hipError_t e = hipMemsetAsync(static_cast<char *>(scratch) + d.zero_begin, 0, d.zero_bytes, st);
+    if (e != hipSuccess) return hip_fail(e, "clearing the scratch counters");
+    return run_pipeline(d.p, yh::kModeDetect, d.blocks, d.q, st, nullptr, nullptr);
+}
+
 int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_t batch,
                     float score_threshold, float iou_threshold, int32_t nms_max_boxes,
                     int32_t max_candidates, void *workspace, size_t workspace_bytes,

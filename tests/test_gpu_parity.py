@@ -300,26 +300,32 @@ def test_candidates_then_select_calls(gpu):
     assert torch.equal(got.class_candidates, want.class_candidates)
 
 
-def test_streaming_variants_agree(gpu, tuning):
-    """The objectness-first kernel (the default; one to several steps per work unit), the
+@pytest.mark.parametrize('obj_mean,hot_mean', [(-1.0, 2.0), (0.0, 0.0), (2.0, -1.0), (9.0, -2.0)])
+def test_streaming_variants_agree(gpu, tuning, obj_mean, hot_mean):
+    """The objectness-first kernel (the default; one to many steps per work unit), the
     wave-private streaming kernel (4 and 8 KiB tiles, 2..4 buffers, few and many work units)
-    and the workgroup-tile kernel find the same candidates."""
+    and the workgroup-tile kernel find the same candidates, from a few percent of the rows
+    surviving the objectness prefilter to all of them."""
     case = cases.v3(size=160)
-    heads = case.heads(77, 3, obj_mean=-1.0)
+    heads = case.heads(77, 3, obj_mean=obj_mean, hot_mean=hot_mean)
     dheads = to_dev(heads, gpu)
-    ref = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+    cap = 2048
+    tuning(detect_kernel=2, stream_tile_kib=1)                # workgroup tiles: the kernel of yh_nms and of dense candidate sets
+    ref = case.head_obj().detect(dheads, 0.4, 0.5, 10, max_candidates=cap, want_class_candidates=True)
+    assert not ref.overflowed()
     want, want_cc = ref.per_image(), ref.class_candidates.clone()
     assert int(ref.count.sum()) > 0
-    for steps in ('1', '3', '50'):
-        tuning(row_steps=int(steps))
-        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+    for steps in (0, 1, 2, 3, 5, 50):
+        tuning(row_steps=steps)
+        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, max_candidates=cap, want_class_candidates=True)
         assert not got.overflowed()
         cases.same_detections(got.per_image(), want)
+        for a, b in zip(got.per_image(), want):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         assert torch.equal(got.class_candidates, want_cc)
-    for ni, nbuf, units in (('8', '3', '8192'), ('8', '2', '64'), ('4', '2', '300'), ('4', '3', '7'),
-                            ('4', '4', '100000'), ('1', '3', '8192')):
-        tuning(detect_kernel=2, stream_tile_kib=int(ni), stream_buffers=int(nbuf), stream_units=int(units))
-        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, want_class_candidates=True)
+    for ni, nbuf, units in ((8, 3, 8192), (8, 2, 64), (4, 2, 300), (4, 3, 7), (4, 4, 100000)):
+        tuning(detect_kernel=2, stream_tile_kib=ni, stream_buffers=nbuf, stream_units=units)
+        got = case.head_obj().detect(dheads, 0.4, 0.5, 10, max_candidates=cap, want_class_candidates=True)
         assert not got.overflowed()
         cases.same_detections(got.per_image(), want)
         assert torch.equal(got.class_candidates, want_cc)

@@ -50,10 +50,28 @@ def select(i):
                                     *hd._output_pointers(outs), st))
 
 
-pipe = y.DetectPipeline(hd, w['thr'], w['iou'], mb)
-print('streaming pass alone   %.2f us' % timed(cand)[0])
-cand(0)
-print('select stage alone     %.2f us (same candidates every time)' % timed(select)[0])
-print('both in one launch     %.2f us' % timed(lambda i: pipe.submit(sets[i % ROT]))[0])
-pipe.flush()
-print('streaming, then select %.2f us (two launches)' % timed(lambda i: (cand(i), select(i)))[0])
+steps_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+for S in steps_list:
+    _abi.set_tuning(row_steps=S)
+    _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, mb, ctypes.byref(nbytes)))
+    ws = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+    hd = y.DetectionHead(C, priors, box_mult, gt_rate)
+    pipe = y.DetectPipeline(hd, w['thr'], w['iou'], mb)
+    t_c = timed(cand)[0]
+    cand(0)
+    t_s = timed(select)[0]
+    t_f = timed(lambda i: pipe.submit(sets[i % ROT]))[0]
+    pipe.flush()
+    lanes = y.DetectLanes(hd, w['thr'], w['iou'], mb, lanes=3, device=dev)
+    for i in range(30):
+        lanes.submit(sets[i % ROT])
+    lanes.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for i in range(1000):
+        lanes.submit(sets[i % ROT])
+    lanes.synchronize()
+    t_l = (time.perf_counter() - t0) / 1000 * 1e6
+    ov = any(d.overflowed() for d in lanes.flush())
+    print('row_steps %2d: streaming pass alone %6.2f us   select alone %6.2f   both in one launch %6.2f   three lanes %6.2f us/step   overflow %s'
+          % (S, t_c, t_s, t_f, t_l, ov), flush=True)

@@ -168,7 +168,8 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
 
-constexpr uint64_t kStreamTargetUnits = 8192;   // wave-private variant: work units (one per wavefront)
+constexpr uint64_t kStreamTargetUnits = 8192;
+constexpr uint64_t kRowsResidentGroups = 512;   // objectness-first variant: two 512-thread workgroups on each of 256 compute units   // wave-private variant: work units (one per wavefront)
 
 // Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
 // relaxed atomics; 0 = the built-in default.
@@ -206,12 +207,21 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         // ones); an image's units are indexed by the candidates -> detections stage, so their
         // number is bounded
         const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
-        uint64_t steps = (uint64_t)knob(kTuneRowSteps, 2);
-        for (;; ++steps) {
+        auto units_per_image = [&](uint64_t steps) {
             uint64_t upi = 0;
             for (int s = 0; s < p.S; ++s) upi += ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
-            if ((upi + waves - 1) / waves * waves <= (uint64_t)yh::kMaxUnitsPerImage) break;
+            return (upi + waves - 1) / waves * waves;
+        };
+        // Default: the fewest steps per unit (down to two) with which the launch's streaming workgroups
+        // are resident at once, two per compute unit: a unit of up to four steps asks for all its
+        // objectness logits at the start, and no workgroup waits for a slot before it can ask.
+        uint64_t steps = (uint64_t)knob(kTuneRowSteps, 0);
+        if (steps == 0) {
+            steps = 4;
+            for (uint64_t cand = 2; cand <= 16; ++cand)
+                if ((uint64_t)B * (units_per_image(cand) / waves) <= kRowsResidentGroups) { steps = cand; break; }
         }
+        while (units_per_image(steps) > (uint64_t)yh::kMaxUnitsPerImage) ++steps;
         p.tile_rows = 64;
         uint32_t upi = 0;
         for (int s = 0; s < p.S; ++s) {

@@ -76,10 +76,10 @@ __device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float
     uint32_t gy = __umulhi(cell, sc.magic_w);
     uint32_t gx = cell - gy * sc.grid_w;
     if (gx >= sc.grid_w) { gx -= sc.grid_w; ++gy; }
-    const float by = ((float)gy + 0.5f) + sigmoidf(ty);
-    const float bx = ((float)gx + 0.5f) + sigmoidf(tx);
-    const float bh = sc.prior_hw[pi][0] + expf(th);
-    const float bw = sc.prior_hw[pi][1] + expf(tw);
+    const float by = ((float)gy + 0.5f) + decode_sigmoid(ty);
+    const float bx = ((float)gx + 0.5f) + decode_sigmoid(tx);
+    const float bh = sc.prior_hw[pi][0] + decode_exp(th);
+    const float bw = sc.prior_hw[pi][1] + decode_exp(tw);
     const float m = sc.mult;
     float4 o;
     o.x = (by - bh / 2.0f) * m;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
             if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
                 if (x >= pf) push_candidate(st, p, b, make_key(c, x, n));
             } else {
-                const float cf = sigmoidf(x) * sigmoidf(rp[C + 4]);
+                const float cf = decode_sigmoid(x) * decode_sigmoid(rp[C + 4]);
                 if (cf >= p.thr) {
                     reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
                         decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
                 const uint32_t rp_off = row0_off + (uint32_t)(rit * K) * 4u;
                 float ty, tx, th, tw, obj;
                 lds_peek5(rp_off + (uint32_t)C * 4u, ty, tx, th, tw, obj);
-                const float so = sigmoidf(obj);
+                const float so = decode_sigmoid(obj);
                 const uint32_t row = row_t + (uint32_t)rit;
                 const int n = (int)(sc.row_base + row);
                 bool have_box = false;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
                     bool hit = false;
                     float cf = 0.0f;
                     if (c < C && x >= pf) {
-                        cf = sigmoidf(x) * so;
+                        cf = decode_sigmoid(x) * so;
                         hit = cf >= p.thr;
                     }
                     const unsigned long long hm = __ballot(hit);
@@ -518,25 +518,46 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
 // matter only if its objectness passes the (conservatively lowered) logit(thr): with the
 // few-percent survival rate of a detector's head, most of the tensor need not be read at all.
 //
-// A workgroup is eight wavefronts on consecutive work units of ONE image (a unit: `steps`
-// steps of 64 rows of one scale).  Per round of two steps:
+// A wavefront owns one work unit: `steps` steps of 64 rows of one image and scale, and walks
+// them on its own (a workgroup is eight such wavefronts on consecutive units of one image and
+// has no barrier).  Per step:
 //   1. a lane reads the objectness logit of one row (one float per K: the memory system
-//      fetches a cache line per row instead of the row, three eighths of the bytes at K = 85);
-//      two steps' logits are requested together (a "round");
-//   2. the rows that pass go into a queue in LDS shared by the eight wavefronts;
-//   3. the wavefronts take the queue's rows four at a time, whichever unit they came from,
-//      so that a unit with many surviving rows does not become the launch's tail: all loads of
-//      the four rows in flight at once (class logits spread over the lanes, the box channels
-//      in lanes 0-3), exact test, box decode, (key, box) staged per wavefront.
-// A wavefront writes what it staged into the private slots of its own unit (any unit of the
-// image will do: keys carry the box row), the 17th and later candidates into the image's
-// list, exactly as k_stream_wave does, and the previous batch's candidates -> detections
-// stage rides in the first q.B workgroups in the same way.
+//      fetches a 128-byte line per row instead of the row); the next step's logits are
+//      requested before this step's are looked at;
+//   2. the rows that pass are appended to the wavefront's ring of survivors in LDS;
+//   3. whenever kRowsBatch survivors are queued (and once more at the end of the unit) they
+//      are worked on together: sixteen lanes per row, four rows per turn, the loads of all
+//      kRowsTurns turns in flight at once (a lane holds kRowsX class logits of its row per turn),
+//      exact sigmoid product and threshold test, box decode once per row with a hit,
+//      (key, box) staged per wavefront.
+// How much is in flight is what matters: with every row of the launch requested at once (one
+// row per lane and everything resident) a survivor's gather queues behind the whole objectness
+// column, so the launch becomes column phase, then gather phase, then stores, each waiting for
+// the slowest of the one before; with a few hundred rows in flight per wavefront and the
+// wavefronts at different steps the gathers travel between the column reads.
+// A wavefront writes what it staged into the private slots of its own unit, the 17th and
+// later candidates into the image's list, exactly as k_stream_wave does, and the previous
+// batch's candidates -> detections stage rides in the first q.B workgroups in the same way.
+#ifdef YH_ROWS_TRACE
+// Measurement build only (tools/trace_rows.py): per-wavefront timestamps of k_detect_rows.
+constexpr int kTraceWaves = 1 << 16, kTraceWords = 8;
+__device__ unsigned long long g_rows_trace[kTraceWaves * kTraceWords];
+#define YH_TRACE_STAMP(var) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = wall_clock64(); } while (0)
+#define YH_TRACE_NOW(var) do { var = wall_clock64(); } while (0)
+#else
+#define YH_TRACE_STAMP(var) do { } while (0)
+#define YH_TRACE_NOW(var) do { } while (0)
+#endif
+
 constexpr int kRowsWaves = kRowsThreads / 64;
-constexpr int kRowsRound = 2;                 // steps whose objectness logits are requested together
-constexpr int kRowsQueue = kRowsRound * kRowsThreads;   // rows one round of a workgroup looks at
-constexpr int kRowsGather = 4;
-constexpr size_t kRowsLds = (size_t)kRowsWaves * kWaveStage * (16 + 8) + (size_t)kRowsQueue * 8 + 16;
+constexpr int kRowsTurns = 4;                 // turns of four rows whose loads are in flight together
+constexpr int kRowsBatch = 4 * kRowsTurns;    // survivors worked on together
+constexpr int kRowsAhead = 4;                 // steps whose objectness logits are requested together (a round)
+constexpr int kRowsList = 128;                // ring of queued survivors per wavefront (a step adds <= 64 to < kRowsBatch)
+constexpr int kRowsX = 6;                     // class logits per lane and row held in registers: 16 * 6 = 96 classes
+constexpr size_t kRowsLds = (size_t)kRowsWaves * ((size_t)kWaveStage * (16 + 8) + (size_t)kRowsList * 8);
+static_assert(kRowsLds <= kRowsLdsMax, "the select stage riding in the launch is planned against kRowsLdsMax");
+static_assert((kRowsList & (kRowsList - 1)) == 0 && kRowsList >= 64 + kRowsBatch, "ring indices are masked");
 
 __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams p, const NmsParams q)
 {
@@ -550,10 +571,8 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     unsigned char *at = s_dyn + (size_t)kRowsWaves * kWaveStage * 16;
     unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(at) + wave * kWaveStage;
     at += (size_t)kRowsWaves * kWaveStage * 8;
-    uint32_t *s_qrow = reinterpret_cast<uint32_t *>(at);            // [kRowsQueue]: (scale << 28) | row inside the scale
-    float *s_qobj = reinterpret_cast<float *>(at + (size_t)kRowsQueue * 4);   // [kRowsQueue]
-    int *s_qn = reinterpret_cast<int *>(at + (size_t)kRowsQueue * 8);         // [3] queue lengths, used in turn
-    if (threadIdx.x < 3) s_qn[threadIdx.x] = 0;
+    uint32_t *s_lrow = reinterpret_cast<uint32_t *>(at) + wave * kRowsList;             // row inside the scale
+    float *s_lobj = reinterpret_cast<float *>(at + (size_t)kRowsWaves * kRowsList * 4) + wave * kRowsList;
 
     const uint32_t g = blockIdx.x - (uint32_t)q.B;
     const int b = (int)(g / p.units);                         // p.units: workgroups per image
@@ -571,7 +590,8 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     const uint32_t row_begin = chunk * steps * 64u;
     uint32_t row_end = has_rows ? row_begin + steps * 64u : row_begin;
     if (row_end > sc.rows_img) row_end = sc.rows_img;
-    const float pf = p.prefilter;
+    const uint32_t nsteps = row_begin < row_end ? (row_end - row_begin + 63u) / 64u : 0u;
+    const float pf = p.prefilter, thr = p.thr;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const long long u = (long long)b * p.upi + ui;
     WaveOut o;
@@ -583,103 +603,176 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     o.cand_cap = p.cand_cap;
     int count = 0;                                            // staged candidates, wave-uniform
     int emitted = 0;                                          // candidates of this unit already written out
+    int head = 0, tail = 0;                                   // the survivors' ring: entries [head, tail), indices masked
+    unsigned long long trB = 0, trC = 0;                      // measurement build: the last batch's data arrived / worked on
+    (void)trB; (void)trC;
+    const int grp = lane >> 4, j = lane & 15;                 // sixteen lanes per row
 
     // rows outside the unit read as NaN: no comparison with the prefilter (-inf for thr <= 0) holds for them
     const float kNoRow = __builtin_nanf("");
     auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : kNoRow; };
-    // The objectness logits of a round are requested one round ahead: while a round's survivors
-    // are gathered and worked on, the next round's column reads are already in flight.
-    float obj_n[kRowsRound];
+
+    // Works on the first n (1 .. kRowsBatch) queued survivors.  Every row read here was queued by this
+    // wavefront from a row < row_end of its own image and scale.
+    auto work = [&](int n) {
+        float xv[kRowsTurns][kRowsX], tb[kRowsTurns], ob[kRowsTurns];
+        uint32_t rw[kRowsTurns];
+        bool val[kRowsTurns];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < kRowsRound; ++j)
-        obj_n[j] = (uint32_t)j < steps ? objectness(row_begin + (uint32_t)j * 64u + (uint32_t)lane) : kNoRow;
-    __syncthreads();
-    for (uint32_t t = 0, round = 0; t < steps; t += kRowsRound, ++round) {
-        int *qn = s_qn + round % 3u;
-        // 1, 2: this round's rows; survivors into the queue
-        float obj_l[kRowsRound];
+        for (int t = 0; t < kRowsTurns; ++t) {
+            val[t] = 4 * t + grp < n;
+            rw[t] = 0u; ob[t] = 0.0f; tb[t] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < kRowsRound; ++j) {
-            obj_l[j] = obj_n[j];
-            const uint32_t tn = t + kRowsRound + (uint32_t)j;
-            obj_n[j] = tn < steps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
+            for (int i = 0; i < kRowsX; ++i) xv[t][i] = 0.0f;
+            if (4 * t < n) {                                  // wave-uniform: the turn holds at least one row
+                const int idx = (head + (val[t] ? 4 * t + grp : 0)) & (kRowsList - 1);   // spare groups re-read entry `head`
+                rw[t] = s_lrow[idx];
+                ob[t] = s_lobj[idx];
+                const float *rp = img + (size_t)rw[t] * K;
+#pragma unroll
+                for (int i = 0; i < kRowsX; ++i) {
+                    const int c = j + 16 * i;
+                    if (c < C) xv[t][i] = rp[c];
+                }
+                tb[t] = rp[C + (j & 3)];                       // t_y, t_x, t_h, t_w in lanes 0-3 of the group
+            }
+        }
+        YH_TRACE_STAMP(trB);
+#pragma unroll
+        for (int t = 0; t < kRowsTurns; ++t) {
+            if (4 * t >= n) break;
+            const float so = decode_sigmoid(ob[t]);
+            const float *rp = img + (size_t)rw[t] * K;
+            const int nrow = (int)(sc.row_base + rw[t]);
+            // exact test of the classes held in registers: a bit per class that is a candidate
+            float cfv[kRowsX];
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int i = 0; i < kRowsX; ++i) {
+                const float x = xv[t][i];
+                cfv[i] = decode_sigmoid(x) * so;
+                if (val[t] && j + 16 * i < C && x >= pf && cfv[i] >= thr) bits |= 1u << i;
+            }
+            bool have_box = false;                            // wave-uniform
+            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+            // stages the lanes' candidates (hit: this lane has one, of class c with confidence cf)
+            auto emit = [&](bool hit, int c, float cf) {
+                const unsigned long long hm = __ballot(hit);
+                if (!have_box) {                              // the box of each group's row, in every lane of the group
+                    const int base = lane & 48;
+                    box = decode_box(p.P, sc, __shfl(tb[t], base, 64), __shfl(tb[t], base + 1, 64),
+                                     __shfl(tb[t], base + 2, 64), __shfl(tb[t], base + 3, 64), rw[t]);
+                    have_box = true;
+                }
+                if (hit) {
+                    const int pos = count + __builtin_popcountll(hm & lanes_below);
+                    s_keys[pos] = make_key(c, cf, nrow);
+                    s_box[pos] = box;
+                }
+                count += __builtin_popcountll(hm);
+                if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
+            };
+            while (__ballot(bits != 0u) != 0ull) {            // a lane's candidates one at a time: mostly one turn of this loop
+                const bool hit = bits != 0u;
+                const int i = hit ? __builtin_ctz(bits) : 0;
+                float cf = cfv[0];
+#pragma unroll
+                for (int k = 1; k < kRowsX; ++k) cf = i == k ? cfv[k] : cf;
+                emit(hit, j + 16 * i, cf);
+                bits &= bits - 1u;
+            }
+            for (int c0 = 16 * kRowsX; c0 < C; c0 += 16) {    // more classes than the registers hold
+                const int c = c0 + j;
+                bool hit = false;
+                float cf = 0.0f;
+                if (val[t] && c < C) {
+                    const float x = rp[c];
+                    if (x >= pf) {
+                        cf = decode_sigmoid(x) * so;
+                        hit = cf >= thr;
+                    }
+                }
+                if (__ballot(hit) != 0ull) emit(hit, c, cf);
+            }
+        }
+        head += n;
+        YH_TRACE_NOW(trC);
+    };
+
+    // A round is kRowsAhead steps whose objectness logits are requested together; the next round's are
+    // in flight while this round's are looked at.  Launch plans aim at one round per unit, with every
+    // workgroup of the launch resident: no wavefront then waits for a second memory round trip before
+    // its survivors' gathers.
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+    (void)tr0; (void)tr1; (void)tr2; (void)tr3; (void)tr4;
+    YH_TRACE_NOW(tr0);
+    float obj_n[kRowsAhead];
+#pragma unroll
+    for (int k = 0; k < kRowsAhead; ++k)
+        obj_n[k] = (uint32_t)k < nsteps ? objectness(row_begin + (uint32_t)k * 64u + (uint32_t)lane) : kNoRow;
+    for (uint32_t t = 0; t < nsteps; t += kRowsAhead) {
+        float obj_c[kRowsAhead];
+#pragma unroll
+        for (int k = 0; k < kRowsAhead; ++k) {
+            obj_c[k] = obj_n[k];
+            const uint32_t tn = t + (uint32_t)(kRowsAhead + k);
+            obj_n[k] = tn < nsteps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
         }
 #pragma unroll
-        for (int j = 0; j < kRowsRound; ++j) {
-            const unsigned long long mask = __ballot(obj_l[j] >= pf);
+        for (int k = 0; k < kRowsAhead; ++k) {
+            const unsigned long long mask = __ballot(obj_c[k] >= pf);
+#ifdef YH_ROWS_TRACE
+            if (t == 0 && k == 0) { asm volatile("" ::"s"(mask)); YH_TRACE_NOW(tr1); }
+#endif
             if (mask) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(qn, __builtin_popcountll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
                 if ((mask >> lane) & 1ull) {
-                    const int e = base + __builtin_popcountll(mask & lanes_below);
-                    s_qrow[e] = ((uint32_t)s << 28) | (row_begin + (t + j) * 64u + (uint32_t)lane);
-                    s_qobj[e] = obj_l[j];
+                    const int e = (tail + __builtin_popcountll(mask & lanes_below)) & (kRowsList - 1);
+                    s_lrow[e] = row_begin + (t + (uint32_t)k) * 64u + (uint32_t)lane;
+                    s_lobj[e] = obj_c[k];
                 }
+                tail += __builtin_popcountll(mask);
             }
+            // mid-walk only when the ring could not take another step: a batch waits for its gathers, which
+            // queue behind whatever objectness reads are still outstanding
+            while (tail - head > kRowsList - 64) work(kRowsBatch);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_qn[(round + 2u) % 3u] = 0;   // last read a round ago, next used two barriers from here
-        const int total = *qn;
-        // 3: the queue's rows, kRowsGather per wavefront and turn
-        for (int e0 = wave * kRowsGather; e0 < total; e0 += kRowsWaves * kRowsGather) {
-            float x0[kRowsGather], x1[kRowsGather], tb[kRowsGather], ob[kRowsGather];
-            uint32_t code[kRowsGather];
-#pragma unroll
-            for (int k = 0; k < kRowsGather; ++k) {
-                if (e0 + k < total) {
-                    code[k] = s_qrow[e0 + k];
-                    ob[k] = s_qobj[e0 + k];
-                    const int es = __builtin_amdgcn_readfirstlane((int)(code[k] >> 28));
-                    const StreamScale &esc = p.sc[es];
-                    const float *rp = esc.src + (long long)b * esc.span + (size_t)(code[k] & 0x0fffffffu) * K;
-                    x0[k] = lane < C ? rp[lane] : 0.0f;
-                    x1[k] = 64 + lane < C ? rp[64 + lane] : 0.0f;
-                    tb[k] = lane < 4 ? rp[C + lane] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kRowsGather; ++k) {
-                if (e0 + k >= total) break;
-                const int es = __builtin_amdgcn_readfirstlane((int)(code[k] >> 28));
-                const StreamScale &esc = p.sc[es];
-                const uint32_t row = code[k] & 0x0fffffffu;
-                const float *rp = esc.src + (long long)b * esc.span + (size_t)row * K;
-                const float so = sigmoidf(ob[k]);
-                const int n = (int)(esc.row_base + row);
-                bool have_box = false;
-                float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int c0 = 0; c0 < C; c0 += 64) {
-                    const int c = c0 + lane;
-                    const float x = c0 == 0 ? x0[k] : (c0 == 64 ? x1[k] : (c < C ? rp[c] : 0.0f));
-                    bool hit = false;
-                    float cf = 0.0f;
-                    if (c < C && x >= pf) {
-                        cf = sigmoidf(x) * so;
-                        hit = cf >= p.thr;
-                    }
-                    const unsigned long long hm = __ballot(hit);
-                    if (hm == 0) continue;
-                    if (!have_box) {                          // the row's box, once, in every lane
-                        box = decode_box(p.P, esc, __shfl(tb[k], 0, 64), __shfl(tb[k], 1, 64), __shfl(tb[k], 2, 64),
-                                         __shfl(tb[k], 3, 64), row);
-                        have_box = true;
-                    }
-                    if (hit) {
-                        const int pos = count + __builtin_popcountll(hm & lanes_below);
-                        s_keys[pos] = make_key(c, cf, n);
-                        s_box[pos] = box;
-                    }
-                    count += __builtin_popcountll(hm);
-                    if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
-                }
-            }
-        }
-        if (t + kRowsRound < steps) __syncthreads();          // the queue is rewritten by the next round
     }
+    YH_TRACE_STAMP(tr2);
+    const int trace_left = tail - head;
+    (void)trace_left;
+    while (tail - head > 0) work(tail - head < kRowsBatch ? tail - head : kRowsBatch);
+    YH_TRACE_STAMP(tr3);
     if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
     if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
+#ifdef YH_ROWS_TRACE
+    YH_TRACE_STAMP(tr4);
+    const unsigned long long wid = (unsigned long long)g * kRowsWaves + wave;
+    if (lane == 0 && wid < (unsigned long long)kTraceWaves) {
+        unsigned long long *tr = g_rows_trace + wid * kTraceWords;
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        tr[0] = tr0; tr[1] = tr1; tr[2] = tr2; tr[3] = tr3; tr[4] = tr4; tr[5] = hwid;
+        tr[6] = ((unsigned long long)(uint32_t)tail << 32) | (uint32_t)trace_left; tr[7] = trB; tr[5] = trC;
+    }
+#endif
 }
+
+#ifdef YH_ROWS_TRACE
+extern "C" int yh_trace_clear(void)
+{
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_rows_trace));
+    if (e == hipSuccess) e = hipMemset(ptr, 0, sizeof(unsigned long long) * kTraceWaves * kTraceWords);
+    return (int)e;
+}
+
+extern "C" int yh_trace_read(void *dst, size_t bytes)
+{
+    const size_t have = sizeof(unsigned long long) * kTraceWaves * kTraceWords;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rows_trace), bytes < have ? bytes : have, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and size: the
 // largest value asked for so far is remembered, a launch within it costs no runtime call.
@@ -734,7 +827,7 @@ __global__ __launch_bounds__(kThreads) void k_decode_full(const StreamParams p, 
     const uint32_t k = l - row * K;
     const long long n = (long long)b * p.N + sc.row_base + row;
     if (k < C) {
-        if (p.conf) p.conf[n * C + k] = sigmoidf(img[l]) * sigmoidf(img[(size_t)row * K + C + 4]);
+        if (p.conf) p.conf[n * C + k] = decode_sigmoid(img[l]) * decode_sigmoid(img[(size_t)row * K + C + 4]);
     } else if (k == C) {
         reinterpret_cast<float4 *>(p.boxes)[n] = decode_box(p.P, sc, img[l], img[l + 1], img[l + 2], img[l + 3], row);
     }

@@ -50,6 +50,8 @@ typedef enum yh_status {
 
 /* bits of the per-image device-side status words written by yh_detect / yh_nms */
 #define YH_STATUS_CANDIDATE_OVERFLOW 1 /* an image had more candidates than max_candidates; result invalid for it */
+#define YH_STATUS_COUNT_SHIFT 8        /* with the overflow bit: bits 8..30 = the image's candidates / 256, rounded up
+                                          (saturating), so that the caller can size max_candidates for a second call */
 
 /* Geometry of the head, the data that distinguishes YOLOv3 from YOLOv2:
  *  prior_hw  : (h, w) in grid units.  YOLOv3: config priors / [8,16,32] with

@@ -365,6 +365,10 @@ def test_candidate_overflow_is_reported_and_rerun(gpu, c_oracle):
     hd = case.head_obj()
     res = hd.detect(to_dev(heads, gpu), 0.3, 0.5, 10, max_candidates=4)
     assert res.overflowed()
+    # the status words say how many candidates the overflowed images had, in units of 256
+    conf = case.head_obj().decode(to_dev(heads, gpu))[1].cpu().numpy()
+    most = int((conf >= np.float32(0.3)).sum(axis=(1, 2)).max())
+    assert res.needed_candidates() == (most + 255) // 256 * 256
     want = c_oracle.detect(case.oracle_cfg(c_oracle), heads, 0.3, 0.5, 10)
     cases.same_detections(res.per_image(), want)
 

@@ -1,0 +1,40 @@
+"""Per-workgroup timeline of the loss kernel's negative branch (measurement build: make -C
+yolo-tf_amd/csrc trace).  Config-3 shape; microseconds since the first workgroup's start."""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, yolo_tf_amd as y
+from yolo_tf_amd import _abi
+_abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), 'libyolohead_trace.so')
+
+dev = torch.device('cuda:0')
+w = bench.WORKLOADS['loss416']
+grids, priors, box_mult, gt_rate = bench.build_head(w)
+B, P, C = w['batch'], len(priors[0]), w['C']
+hd = y.DetectionHead(C, priors, box_mult, gt_rate)
+lib = _abi.load()
+lib.yh_trace_loss_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+sets = [y.synth.torch_heads(dev, i, B, grids, P, C) for i in range(8)]
+gts = [torch.from_numpy(y.synth.make_ground_truth(70 + i, B, w['G'], w['pad'], w['size'], C)).to(dev) for i in range(8)]
+for i in range(10):
+    if i == 9:
+        torch.cuda.synchronize()
+        assert lib.yh_trace_loss_read(None, 0, 1) == 0
+    hd.loss(sets[i % 8], gts[i % 8], 1., 1., 5., 1., 0.5, True)
+torch.cuda.synchronize()
+tr = np.zeros((1 << 14, 8), np.uint64)
+assert lib.yh_trace_loss_read(tr.ctypes.data, tr.nbytes, 0) == 0
+tr = tr[tr[:, 7] > 0]
+t = tr[:, :6].astype(np.float64) / 100.0
+t -= t[:, 0].min()
+def q(x):
+    return 'min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' % (x.min(), *np.percentile(x, [10, 50, 90]), x.max())
+print('%d negative-branch workgroups (wavefront 0 of each)' % len(t))
+for name, x in (('start', t[:, 0]), ('GT staged at', t[:, 1]), ('GT converted (barrier) at', t[:, 2]), ('IoU loop done at', t[:, 3]),
+                ('cross-entropy done at', t[:, 4]), ('end', t[:, 5]), ('staging', t[:, 1] - t[:, 0]), ('conversion', t[:, 2] - t[:, 1]),
+                ('setup + IoU loop', t[:, 3] - t[:, 2]), ('cross-entropy', t[:, 4] - t[:, 3]), ('reduce + write', t[:, 5] - t[:, 4])):
+    print('  %-28s %s' % (name, q(x)))
+for s in range(3):
+    m = tr[:, 6] == s
+    print('  scale %d: %4d workgroups, IoU loop %s' % (s, m.sum(), q((t[:, 3] - t[:, 2])[m])))

@@ -11,6 +11,7 @@ YH_MAX_CLASSES = 4096
 YH_MAX_BOXES_PER_IMAGE = 1 << 20
 YH_MAX_NMS_BOXES = 512
 YH_STATUS_CANDIDATE_OVERFLOW = 1
+YH_STATUS_COUNT_SHIFT = 8
 YH_STATIC_SCRATCH_BYTES = 8 << 20
 
 YH_OK = 0

@@ -762,7 +762,7 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
         sc.blk_begin = blk;
         sc.gt_rate = cfg->gt_rate[s];
         std::memcpy(sc.prior_hw, cfg->prior_hw[s], sizeof(sc.prior_hw));
-        blk += (sc.rows_img + yh::kLossNegThreads - 1) / yh::kLossNegThreads;
+        blk += (sc.rows_img + yh::kLossNegRows - 1) / yh::kLossNegRows;
         row_base += sc.rows_img;
     }
     p.blocks_per_img = (int32_t)blk;

@@ -115,6 +115,19 @@ enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
 hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks, hipStream_t st,
                          const struct NmsParams *fused = nullptr);
 
+// Status word of an image (yolohead.h): the overflow bit and, with it, how many candidates the
+// image had (stored and dropped), in units of 256, saturating.
+__device__ __forceinline__ int32_t image_status(int stored, int raw, int cap)
+{
+    // `stored` counts what this stage read: slot candidates plus min(raw, cap) list entries; `raw` is the
+    // list's counter, which kept counting past the capacity
+    if (!(stored > cap || raw > cap)) return 0;
+    const long long total = (long long)stored + (raw > cap ? (long long)raw - cap : 0);
+    long long units = (total + 255) >> 8;
+    units = units > 0x7fffff ? 0x7fffff : units;
+    return (int32_t)(YH_STATUS_CANDIDATE_OVERFLOW | (units << YH_STATUS_COUNT_SHIFT));
+}
+
 // ---- candidates -> detections --------------------------------------------
 struct NmsParams {
     int32_t B, C, N;
@@ -201,6 +214,8 @@ size_t loss_lds_bytes(int pad, int occ_words);      // dynamic LDS of the loss k
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;
-constexpr int kLossPosGtPerBlock = 4;   // one wave per ground-truth box
+constexpr int kLossBoxes = 1;            // box rows per lane of the negative branch
+constexpr int kLossNegRows = kLossNegThreads * kLossBoxes;   // box rows per workgroup
+constexpr int kLossPosGtPerBlock = 16;  // ground-truth rows per workgroup of the positive branch
 
 }  // namespace yh

@@ -13,7 +13,16 @@
 
 namespace yh {
 
-constexpr int kPosThreads = 64 * kLossPosGtPerBlock;
+#ifdef YH_ROWS_TRACE
+// Measurement build only (tools/trace_loss.py): per-workgroup timestamps of the negative branch.
+constexpr int kLossTraceGroups = 1 << 14, kLossTraceWords = 8;
+__device__ unsigned long long g_loss_trace[kLossTraceGroups * kLossTraceWords];
+#define YH_LT(var) do { var = wall_clock64(); } while (0)
+#else
+#define YH_LT(var) do { } while (0)
+#endif
+
+constexpr int kPosThreads = kLossNegThreads;     // the positive branch shares the negative branch's launch
 constexpr int kPairStride = 12;              // floats per pair of ground-truth rows in LDS (16-byte aligned)
 constexpr float kLossFastBound = 0x1p40f;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -99,8 +108,8 @@ __device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int
 }
 
 // ---------------------------------------------------------------- negative
-// B * blocks_per_img workgroups; one owns 256 consecutive box rows of one scale
-// of one image.  s_raw: 5 * pad floats (GT corners + area at this scale)
+// B * blocks_per_img workgroups; one owns kLossNegRows consecutive box rows of one scale
+// of one image, kLossBoxes per lane.  s_raw: 5 * pad floats (GT corners + area at this scale)
 // followed by the cell-occupancy bitmap of the scale.
 //
 // EXACT_MAX = false (the caller does not ask for the IoU maxima): only the
@@ -126,6 +135,9 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     float *s_gt = s_pair + (size_t)((p.pad + 1) >> 1) * kPairStride;    // [pad][5]: y1 x1 y2 x2 area
     uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
 
+    unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
+    (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
+    YH_LT(lt0);
     const int tid = threadIdx.x;
     const int b = block / p.blocks_per_img;
     const uint32_t r = block - (uint32_t)b * p.blocks_per_img;
@@ -134,15 +146,13 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     for (int i = 1; i < YH_MAX_SCALES; ++i)
         if (i < p.S && r >= p.sc[i].blk_begin) s = i;
     const LossScale &sc = p.sc[s];
-    const uint32_t row = (r - sc.blk_begin) * kLossNegThreads + tid;
     const int C = p.C, K = p.K, P = p.P, H = sc.H, W = sc.W;
     const float *gt = p.gt + (long long)b * p.pad * 5;
-
-    const bool in_range = row < sc.rows_img;
 
     const int occ_words = (H * W + 31) >> 5;
     for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
     const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
+    YH_LT(lt1);
     const float rate = sc.gt_rate;
     int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
     for (int g = tid; g < G; g += kLossNegThreads) {           // row g is rewritten in place by its only reader
@@ -170,22 +180,33 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         }
     }
     const bool gt_in_bounds = __syncthreads_and(in_bounds) != 0;
+    YH_LT(lt2);
 
-    // The objectness logit is asked for here, after the ground-truth round trip (memory loads
-    // return in issue order: an earlier request would hold that round trip back), and is not
-    // needed before the IoU loop below has run: the loop hides its latency.
-    float obj = 0.0f;
-    if (in_range) obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
+    // The objectness logits are asked for here, after the ground-truth round trip (memory loads
+    // return in issue order: an earlier request would hold that round trip back), and are not
+    // needed before the IoU loop below has run: the loop hides their latency.
+    // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart: every
+    // ground-truth pair read from LDS serves all of them.
+    const uint32_t row0 = (r - sc.blk_begin) * kLossNegRows;
+    uint32_t row[kLossBoxes];
+    bool in_range[kLossBoxes];
+    float obj[kLossBoxes];
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) {
+        row[i] = row0 + (uint32_t)(i * kLossNegThreads + tid);
+        in_range[i] = row[i] < sc.rows_img;
+        obj[i] = 0.0f;
+        if (in_range[i]) obj[i] = sc.head[((long long)b * sc.rows_img + row[i]) * K + C + 4];
+    }
 
     // the workgroup's run of the gradient tensor: `lead` single floats up to 16-byte alignment,
     // nb 16-byte blocks, then fewer than four single floats
-    const uint32_t row0 = (r - sc.blk_begin) * kLossNegThreads;
     float *gdst = nullptr;
     float4 *gdst4 = nullptr;
     uint32_t gtotal = 0, lead = 0, nb = 0, filled = 0;
     float gscale = 0.0f;
     if (GRAD) {
-        const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegThreads ? sc.rows_img - row0 : (uint32_t)kLossNegThreads;
+        const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegRows ? sc.rows_img - row0 : (uint32_t)kLossNegRows;
         gdst = sc.grad + ((long long)b * sc.rows_img + row0) * K;
         gtotal = nrows * (uint32_t)K;
         lead = (4u - (uint32_t)((reinterpret_cast<uintptr_t>(gdst) >> 2) & 3u)) & 3u;
@@ -196,105 +217,139 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         if (p.normalize) gscale = gscale / (float)G;
     }
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto fill_some = [&]() {                                    // kLossBoxes 16-byte stores of zeros per lane
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i) {
+            const uint32_t at = filled * (uint32_t)kLossNegThreads + (uint32_t)tid;
+            if (at < nb) gdst4[at] = zero4;
+            ++filled;
+        }
+    };
 
-    float contrib = 0.0f;
-    bool counted_row = false;
-    if (in_range) {
-        const uint32_t cell = row / (uint32_t)P;
-        const uint32_t pi = row - cell * (uint32_t)P;
-        const uint32_t cy = cell / (uint32_t)W, cx = cell - cy * (uint32_t)W;
-        const bool occupied = (s_occ[cell >> 5] >> (cell & 31)) & 1u;
-        float m = __builtin_nanf("");
-        bool counted = false;                 // the box enters the no-object sum
-        if (!occupied) {
-            // YOLOv3.py:246-257: L = a_yx - a_hw/2 and U = a_yx + a_hw/2 are then used
-            // as (centre, size): corners L - U/2 and L + U/2.
+    // each box: the reference's no-object box (YOLOv3.py:246-257: L = a_yx - a_hw/2 and
+    // U = a_yx + a_hw/2 are then used as (centre, size): corners L - U/2 and L + U/2)
+    float by1[kLossBoxes], bx1[kLossBoxes], by2[kLossBoxes], bx2[kLossBoxes], aarea[kLossBoxes];
+    bool live[kLossBoxes];                                      // in range and in a cell without a GT centre
+    bool dims_ok = true;
+    bool any_live = false;
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) {
+        by1[i] = bx1[i] = by2[i] = bx2[i] = aarea[i] = 0.0f;
+        live[i] = false;
+        if (in_range[i]) {
+            const uint32_t cell = row[i] / (uint32_t)P;
+            const uint32_t pi = row[i] - cell * (uint32_t)P;
+            const uint32_t cy = cell / (uint32_t)W, cx = cell - cy * (uint32_t)W;
+            live[i] = !((s_occ[cell >> 5] >> (cell & 31)) & 1u);
             const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
-            float ah = 0.0f, aw = 0.0f;                   // uniform walk: scalar reads of the parameter block
+            float ah = 0.0f, aw = 0.0f;                       // uniform walk: scalar reads of the parameter block
             for (int q = 0; q < P; ++q)
                 if (pi == (uint32_t)q) { ah = sc.prior_hw[q][0]; aw = sc.prior_hw[q][1]; }
             const float ly = ay - ah / 2.0f, lx = ax - aw / 2.0f;
             const float uy = ay + ah / 2.0f, ux = ax + aw / 2.0f;
-            const float by1 = ly - uy / 2.0f, bx1 = lx - ux / 2.0f;
-            const float by2 = ly + uy / 2.0f, bx2 = lx + ux / 2.0f;
-            const float aarea = (by2 - by1) * (bx2 - bx1);
-            if (EXACT_MAX) {
-                m = -INFINITY;
-                bool any_nan = false;
-                for (int g = 0; g < G; ++g) {
-                    const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
-                    const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
-                    const float garea = s_gt[g * 5 + 4];
-                    // intersection NOT clamped at zero (YOLOv3.py:286)
-                    const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
-                    const float iou = inter / ((aarea + garea) - inter);
-                    if (iou != iou) any_nan = true;
-                    else if (iou > m) m = iou;
-                }
-                if (any_nan) m = __builtin_nanf("");
-                counted = m <= p.ignore_thr;
-            } else {
-                // Division-free pass, two ground-truth rows per step in packed arithmetic.  With
-                // d = sign(uni) * inter - thr * |uni| (one rounding) and the margin
-                // m = 2^-20 * max(1, thr) * |uni| + 2^-100:  d > m implies RN(inter / uni) > thr and
-                // d < -m implies the opposite (the roundings involved stay below 2^-22 relative; the
-                // constant keeps tiny unions out).  e = d - m and h = max(d - m, -d - m) are folded
-                // into a running maximum and minimum: some e > 0 means "masked", every h > 0 means
-                // every pair was decided.  That bookkeeping needs NaN-free values, which the bounds
-                // on the operands guarantee (no product can overflow); otherwise, and for a pair
-                // inside the margin, the exact walk below decides.
-                const float thr = p.ignore_thr;
-                const bool fast = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f &&
-                                  fabsf(ah) < kLossFastBound && fabsf(aw) < kLossFastBound;
-                const float mfac = 0x1p-20f * fmaxf(1.0f, thr);
-                float e_max = -INFINITY, h_min = fast ? INFINITY : -INFINITY;
-                const int pairs = fast ? (G + 1) >> 1 : 0;
-                const f2 nthr = {-thr, -thr}, mf = {mfac, mfac}, tiny = {0x1p-100f, 0x1p-100f};
-                const f2 aa = {aarea, aarea};
-                for (int j = 0; j < pairs; ++j) {
-                    if (GRAD && !(j & 1)) {
-                        const uint32_t i = filled * (uint32_t)kLossNegThreads + (uint32_t)tid;
-                        if (i < nb) gdst4[i] = zero4;
-                        ++filled;
-                    }
-                    const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'
-                    const float4 hi = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride + 4);  // y2 y2' x2 x2'
-                    const float2 ar = *reinterpret_cast<const float2 *>(s_pair + j * kPairStride + 8);
-                    const f2 dy = f2{vmin(hi.x, by2), vmin(hi.y, by2)} - f2{vmax(lo.x, by1), vmax(lo.y, by1)};
-                    const f2 dx = f2{vmin(hi.z, bx2), vmin(hi.w, bx2)} - f2{vmax(lo.z, bx1), vmax(lo.w, bx1)};
-                    const f2 inter = dy * dx;
-                    const f2 uni = (aa + f2{ar.x, ar.y}) - inter;
-                    const f2 au = {fabsf(uni.x), fabsf(uni.y)};
-                    const f2 si = {__uint_as_float(__float_as_uint(inter.x) ^ (__float_as_uint(uni.x) & 0x80000000u)),
-                                   __uint_as_float(__float_as_uint(inter.y) ^ (__float_as_uint(uni.y) & 0x80000000u))};
-                    const f2 d = __builtin_elementwise_fma(nthr, au, si);
-                    const f2 m = __builtin_elementwise_fma(mf, au, tiny);
-                    const f2 e = d - m, f = -d - m;
-                    e_max = fmaxf(e_max, fmaxf(e.x, e.y));
-                    h_min = fminf(h_min, fminf(fmaxf(e.x, f.x), fmaxf(e.y, f.y)));
-                }
-                int masked = e_max > 0.0f ? 1 : 0;
-                const bool recheck = !(h_min > 0.0f);
-                if (recheck) {                    // rare: the exact walk decides
-                    masked = 0;
-                    for (int g = 0; g < G; ++g) {
-                        const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
-                        const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
-                        const float garea = s_gt[g * 5 + 4];
-                        const float inter = (vmin(gy2, by2) - vmax(gy1, by1)) * (vmin(gx2, bx2) - vmax(gx1, bx1));
-                        const float iou = inter / ((aarea + garea) - inter);
-                        masked |= (iou != iou) | (iou > thr);
-                    }
-                }
-                counted = !masked;
-            }
+            by1[i] = ly - uy / 2.0f; bx1[i] = lx - ux / 2.0f;
+            by2[i] = ly + uy / 2.0f; bx2[i] = lx + ux / 2.0f;
+            aarea[i] = (by2[i] - by1[i]) * (bx2[i] - bx1[i]);
+            dims_ok = dims_ok && fabsf(ah) < kLossFastBound && fabsf(aw) < kLossFastBound;
+            any_live = any_live || live[i];
         }
-        if (counted) contrib = sigmoid_ce(obj, 0.0f);
-        counted_row = counted;
-        if (EXACT_MAX) p.iou_max[(long long)b * p.N + sc.row_base + row] = m;
-        if (p.noobj_mask) p.noobj_mask[(long long)b * p.N + sc.row_base + row] = counted ? 1 : 0;
     }
 
+    float m[kLossBoxes];
+    bool counted[kLossBoxes];                                   // the box enters the no-object sum
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) { m[i] = __builtin_nanf(""); counted[i] = false; }
+    // the exact walk of one box: IoU maximum (NaN if any IoU is NaN), intersection NOT clamped at zero (YOLOv3.py:286)
+    auto exact_max = [&](int i) {
+        float mx = -INFINITY;
+        bool any_nan = false;
+        for (int g = 0; g < G; ++g) {
+            const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
+            const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
+            const float garea = s_gt[g * 5 + 4];
+            const float inter = (vmin(gy2, by2[i]) - vmax(gy1, by1[i])) * (vmin(gx2, bx2[i]) - vmax(gx1, bx1[i]));
+            const float iou = inter / ((aarea[i] + garea) - inter);
+            if (iou != iou) any_nan = true;
+            else if (iou > mx) mx = iou;
+        }
+        return any_nan ? __builtin_nanf("") : mx;
+    };
+    if (EXACT_MAX) {
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i) {
+            if (live[i]) {
+                m[i] = exact_max(i);
+                counted[i] = m[i] <= p.ignore_thr;
+            }
+        }
+    } else if (any_live) {
+        // Division-free pass, two ground-truth rows per step in packed arithmetic.  With the
+        // margin eps = 2^-20 * max(1, thr):
+        //   a = inter - (thr + eps) * uni,  e = uni * a:   e > 0  implies  RN(inter / uni) > thr,
+        //   b = inter - (thr - eps) * uni,  f = -uni * b:  f > 0  implies  RN(inter / uni) < thr
+        // for either sign of the union (a product with uni keeps or flips the inequality exactly as
+        // the division by uni does; one rounding in a and b, none that could change the sign of e
+        // or f short of an underflow to zero, and a zero decides nothing).  e is folded into a
+        // running maximum (some e > 0: masked), max(e, f) into a running minimum (every pair
+        // decided).  That bookkeeping needs NaN-free values, which the bounds on the operands
+        // guarantee (no product can overflow); otherwise, and for a pair inside the margin or
+        // with a zero union, the exact walk decides.
+        const float thr = p.ignore_thr;
+        const bool fast = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f && dims_ok;
+        const float eps = 0x1p-20f * fmaxf(1.0f, thr);
+        float e_max[kLossBoxes], h_min[kLossBoxes];
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i) { e_max[i] = -INFINITY; h_min[i] = fast ? INFINITY : -INFINITY; }
+        const int pairs = fast ? (G + 1) >> 1 : 0;
+        const f2 c_hi = {-(thr + eps), -(thr + eps)}, c_lo = {-(thr - eps), -(thr - eps)};
+        auto pair_step = [&](int j) {
+            const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'
+            const float4 hi = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride + 4);  // y2 y2' x2 x2'
+            const float2 ar = *reinterpret_cast<const float2 *>(s_pair + j * kPairStride + 8);
+#pragma unroll
+            for (int i = 0; i < kLossBoxes; ++i) {
+                const f2 dy = f2{vmin(hi.x, by2[i]), vmin(hi.y, by2[i])} - f2{vmax(lo.x, by1[i]), vmax(lo.y, by1[i])};
+                const f2 dx = f2{vmin(hi.z, bx2[i]), vmin(hi.w, bx2[i])} - f2{vmax(lo.z, bx1[i]), vmax(lo.w, bx1[i])};
+                const f2 inter = dy * dx;
+                const f2 uni = (f2{aarea[i], aarea[i]} + f2{ar.x, ar.y}) - inter;
+                const f2 a = __builtin_elementwise_fma(c_hi, uni, inter);
+                const f2 b2 = __builtin_elementwise_fma(c_lo, uni, inter);
+                const f2 e = uni * a, f = -uni * b2;
+                e_max[i] = fmaxf(e_max[i], fmaxf(e.x, e.y));
+                h_min[i] = fminf(h_min[i], fminf(fmaxf(e.x, f.x), fmaxf(e.y, f.y)));
+            }
+        };
+        int j = 0;
+        for (; j + 1 < pairs; j += 2) {                        // two steps per turn: the second step's LDS reads travel
+            if (GRAD) fill_some();                             //  while the first step computes
+            pair_step(j);
+            pair_step(j + 1);
+        }
+        if (j < pairs) pair_step(j);
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i) {
+            if (live[i]) {
+                bool masked = e_max[i] > 0.0f;
+                if (!(h_min[i] > 0.0f)) {                      // rare: the exact walk decides
+                    const float mx = exact_max(i);
+                    masked = (mx != mx) || mx > thr;
+                }
+                counted[i] = !masked;
+            }
+        }
+    }
+    YH_LT(lt3);
+    float contrib = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) {
+        if (in_range[i]) {
+            if (counted[i]) contrib += sigmoid_ce(obj[i], 0.0f);
+            if (EXACT_MAX) p.iou_max[(long long)b * p.N + sc.row_base + row[i]] = m[i];
+            if (p.noobj_mask) p.noobj_mask[(long long)b * p.N + sc.row_base + row[i]] = counted[i] ? 1 : 0;
+        }
+    }
+
+    YH_LT(lt4);
     // block sum, fixed order
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
@@ -306,19 +361,45 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         if (e < gtotal) gdst[e] = 0.0f;
     }
     __syncthreads();
-    if (GRAD && counted_row) gdst[(row - row0) * (uint32_t)K + (uint32_t)(C + 4)] = sigmoidf(obj) * gscale;
+    if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i)
+            if (counted[i]) gdst[(row[i] - row0) * (uint32_t)K + (uint32_t)(C + 4)] = sigmoidf(obj[i]) * gscale;
+    }
     if (tid == 0) {
         float acc = s_val[0];
         for (int w = 1; w < kLossNegThreads / 64; ++w) acc += s_val[w];
         p.neg_partial[(long long)b * p.blocks_per_img + r] = acc;
     }
+#ifdef YH_ROWS_TRACE
+    YH_LT(lt5);
+    if ((tid & 63) == 0 && block < (uint32_t)kLossTraceGroups && (tid >> 6) < 1) {
+        unsigned long long *tr = g_loss_trace + (size_t)block * kLossTraceWords;
+        tr[0] = lt0; tr[1] = lt1; tr[2] = lt2; tr[3] = lt3; tr[4] = lt4; tr[5] = lt5; tr[6] = (unsigned long long)s; tr[7] = 1;
+    }
+#endif
 }
+
+#ifdef YH_ROWS_TRACE
+extern "C" int yh_trace_loss_read(void *dst, size_t bytes, int clear)
+{
+    const size_t have = sizeof(unsigned long long) * kLossTraceGroups * kLossTraceWords;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_loss_trace));
+    if (e != hipSuccess) return (int)e;
+    if (clear) return (int)hipMemset(ptr, 0, have);
+    return (int)hipMemcpy(dst, ptr, bytes < have ? bytes : have, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Target assignment of one ground-truth row (yc, xc, h, w, class in pixels): best
 // prior per scale by the reference's IoU (YOLOv3.py:159-177: intersection not
 // clamped, anchor area = prod(hw); argmax = first maximum), then the scale
 // (YOLOv3.py:185-189: scale s < S-1 takes the GT when it beats every other scale
-// strictly; everything else goes to the last scale).  All wave-uniform.
+// strictly; everything else goes to the last scale).  Every lane may hold a row of its
+// own: the parameter block is only read at uniform indices (an indexed read by a per-lane
+// scale or prior would be a vector load from memory with a round trip of its own), and
+// what belongs to the chosen scale and prior is picked with selects.
 struct GtAssign {
     int s, p;            // scale and prior
     uint32_t row;        // box row inside the scale: (cy * W + cx) * P + p
@@ -334,11 +415,14 @@ __device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *
     const float y = gtrow[0], x = gtrow[1], h = gtrow[2], w = gtrow[3];
     GtAssign a;
     a.label = (int)gtrow[4];                                  // tf.cast(float -> int32) truncates
-    float best_iou[YH_MAX_SCALES];
-    int best_p[YH_MAX_SCALES];
+    float best_iou[YH_MAX_SCALES], sgy[YH_MAX_SCALES], sgx[YH_MAX_SCALES], sgh[YH_MAX_SCALES], sgw[YH_MAX_SCALES];
+    float sph[YH_MAX_SCALES], spw[YH_MAX_SCALES];
+    int best_p[YH_MAX_SCALES], srow[YH_MAX_SCALES];
+    bool sin[YH_MAX_SCALES];
 #pragma unroll
     for (int s = 0; s < YH_MAX_SCALES; ++s) {
-        best_iou[s] = 0.0f; best_p[s] = 0;
+        best_iou[s] = 0.0f; best_p[s] = 0; sgy[s] = sgx[s] = sgh[s] = sgw[s] = 0.0f; sph[s] = spw[s] = 1.0f;
+        srow[s] = 0; sin[s] = false;
         if (s < S) {
             const float rate = p.sc[s].gt_rate;
             const float gy = y / rate, gx = x / rate, gh = h / rate, gw = w / rate;
@@ -352,8 +436,12 @@ __device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *
                 const float ay2 = ay + ah / 2.0f, ax2 = ax + aw / 2.0f;
                 const float inter = (fminf(gy2, ay2) - fmaxf(gy1, ay1)) * (fminf(gx2, ax2) - fmaxf(gx1, ax1));
                 const float iou = inter / ((ah * aw + garea) - inter);
-                if (q == 0 || iou > best_iou[s]) { best_iou[s] = iou; best_p[s] = q; }
+                if (q == 0 || iou > best_iou[s]) { best_iou[s] = iou; best_p[s] = q; sph[s] = ah; spw[s] = aw; }
             }
+            sgy[s] = gy; sgx[s] = gx; sgh[s] = gh; sgw[s] = gw;
+            const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+            sin[s] = cy >= 0 && cy < p.sc[s].H && cx >= 0 && cx < p.sc[s].W;
+            srow[s] = (cy * p.sc[s].W + cx) * P + best_p[s];
         }
     }
     int ssel = S - 1;
@@ -368,29 +456,76 @@ __device__ __forceinline__ GtAssign assign_gt(const LossParams &p, const float *
             if (wins) { ssel = s; found = true; }
         }
     }
-    int psel = 0;
+    a.s = ssel; a.p = 0; a.row = 0u; a.inside = false;
+    a.gy = a.gx = a.gh = a.gw = 0.0f; a.prior_h = a.prior_w = 1.0f;
 #pragma unroll
-    for (int s = 0; s < YH_MAX_SCALES; ++s) if (s == ssel) psel = best_p[s];
-    // wave-uniform by construction; saying so keeps the parameter-block reads below scalar
-    ssel = __builtin_amdgcn_readfirstlane(ssel);
-    psel = __builtin_amdgcn_readfirstlane(psel);
-    const LossScale &sc = p.sc[ssel];
-    const float rate = sc.gt_rate;
-    a.s = ssel; a.p = psel;
-    a.gy = y / rate; a.gx = x / rate; a.gh = h / rate; a.gw = w / rate;
-    const int cy = (int)floorf(a.gy), cx = (int)floorf(a.gx);
-    a.inside = cy >= 0 && cy < sc.H && cx >= 0 && cx < sc.W;
-    a.row = a.inside ? (uint32_t)((cy * sc.W + cx) * P + psel) : 0u;
-    a.prior_h = sc.prior_hw[psel][0]; a.prior_w = sc.prior_hw[psel][1];
+    for (int s = 0; s < YH_MAX_SCALES; ++s) {
+        if (s == ssel) {
+            a.p = best_p[s];
+            a.gy = sgy[s]; a.gx = sgx[s]; a.gh = sgh[s]; a.gw = sgw[s];
+            a.prior_h = sph[s]; a.prior_w = spw[s];
+            a.inside = sin[s];
+            a.row = sin[s] ? (uint32_t)srow[s] : 0u;
+        }
+    }
     return a;
 }
 
+// What the positive branch keeps per ground-truth row between its two phases.
+struct PosLds {
+    const float *rowp[kLossPosGtPerBlock];     // the assigned head row; null: no term (centre outside the grid, or no row)
+    float *growp[kLossPosGtPerBlock];          // the same row of the gradient tensor (backward)
+    float fy[kLossPosGtPerBlock], fx[kLossPosGtPerBlock];   // cross-entropy labels of t_y, t_x: the centre's offset inside its cell
+    float lh[kLossPosGtPerBlock], lw[kLossPosGtPerBlock];   // regression targets of t_h, t_w: log(size / prior)
+    int label[kLossPosGtPerBlock];
+};
+
+// Phase one: a lane per ground-truth row of this workgroup's share (rows blk * kLossPosGtPerBlock ...),
+// assignment and targets into LDS.  Returns the number of rows in the share.  Ends with a barrier.
+__device__ __forceinline__ int pos_assign(const LossParams &p, int b, int blk, int G, PosLds &l, bool want_grad)
+{
+    const int tid = threadIdx.x;
+    const int g0 = blk * kLossPosGtPerBlock;
+    int n = G - g0;
+    n = n < 0 ? 0 : (n > kLossPosGtPerBlock ? kLossPosGtPerBlock : n);
+    if (tid < kLossPosGtPerBlock) {
+        const float *rowp = nullptr;
+        float *growp = nullptr;
+        float fy = 0.0f, fx = 0.0f, lh = 0.0f, lw = 0.0f;
+        int label = -1;
+        if (tid < n) {
+            const GtAssign a = assign_gt(p, p.gt + ((long long)b * p.pad + g0 + tid) * 5);
+            if (a.inside) {
+                // the head of the chosen scale: uniform reads of the parameter block, selects
+                const float *base = nullptr;
+                float *gbase = nullptr;
+                long long rows_img = 0;
+#pragma unroll
+                for (int s = 0; s < YH_MAX_SCALES; ++s)
+                    if (s < p.S && s == a.s) { base = p.sc[s].head; gbase = p.sc[s].grad; rows_img = p.sc[s].rows_img; }
+                const long long at = ((long long)b * rows_img + a.row) * p.K;
+                rowp = base + at;
+                growp = want_grad ? gbase + at : nullptr;
+                fy = a.gy - floorf(a.gy); fx = a.gx - floorf(a.gx);
+                lh = logf(a.gh / a.prior_h); lw = logf(a.gw / a.prior_w);
+                label = a.label;
+            }
+        }
+        l.rowp[tid] = rowp; l.growp[tid] = growp;
+        l.fy[tid] = fy; l.fx[tid] = fx; l.lh[tid] = lh; l.lw[tid] = lw; l.label[tid] = label;
+    }
+    __syncthreads();
+    return n;
+}
+
 // ---------------------------------------------------------------- positive
-// B * pos_blocks workgroups; one wavefront per ground-truth row.  Every lane
-// evaluates the (cheap) assignment redundantly, then the lanes split the K
-// channels of the assigned head row.
+// B * pos_blocks workgroups; one takes kLossPosGtPerBlock ground-truth rows of one image.
+// Phase one (pos_assign): a lane per row.  Phase two: the rows' K channels as one flat list
+// of (row, channel) items spread over the workgroup's lanes, so that the cross-entropy code
+// runs on full wavefronts (a wavefront per row ran it twice on 85 of 128 lanes, after every
+// lane had repeated the row's assignment).
 __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t block, float *s_val, int *s_idx,
-                                               float (*s_part)[3])
+                                               float (*s_part)[3], PosLds &l)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (int)(block / (uint32_t)p.pos_blocks);
@@ -398,33 +533,29 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     const float *gt = p.gt + (long long)b * p.pad * 5;
     const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
     if (blk == 0 && tid == 0) p.gcount[b] = G;
-
-    const int g = blk * kLossPosGtPerBlock + wave;
+    const int n = pos_assign(p, b, blk, G, l, false);
+    const int C = p.C, K = p.K;
+    const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;   // item -> row by multiply-high (items < 2^17)
     float coord = 0.0f, cls = 0.0f, obj = 0.0f;
-    if (g < G) {
-        const int C = p.C, K = p.K;
-        const GtAssign a = assign_gt(p, gt + g * 5);
-        if (a.inside) {
-            const LossScale &sc = p.sc[a.s];
-            const float *rowp = sc.head + (long long)b * sc.rows_img * K + (long long)a.row * K;
-            for (int k = lane; k < K; k += 64) {
-                const float v = rowp[k];
-                if (k < C) {
-                    cls += sigmoid_ce(v, k == a.label ? 1.0f : 0.0f);
-                } else if (k == C) {
-                    coord += sigmoid_ce(v, a.gy - floorf(a.gy));
-                } else if (k == C + 1) {
-                    coord += sigmoid_ce(v, a.gx - floorf(a.gx));
-                } else if (k == C + 2) {
-                    const float d = v - logf(a.gh / a.prior_h);
-                    coord += 0.5f * (d * d);
-                } else if (k == C + 3) {
-                    const float d = v - logf(a.gw / a.prior_w);
-                    coord += 0.5f * (d * d);
-                } else {
-                    obj += sigmoid_ce(v, 1.0f);
-                }
-            }
+    for (int it = tid; it < n * K; it += kPosThreads) {
+        const int gl = (int)__umulhi((uint32_t)it, magic), k = it - gl * K;
+        const float *rowp = l.rowp[gl];
+        if (!rowp) continue;
+        const float v = rowp[k];
+        if (k < C) {
+            cls += sigmoid_ce(v, k == l.label[gl] ? 1.0f : 0.0f);
+        } else if (k == C) {
+            coord += sigmoid_ce(v, l.fy[gl]);
+        } else if (k == C + 1) {
+            coord += sigmoid_ce(v, l.fx[gl]);
+        } else if (k == C + 2) {
+            const float d = v - l.lh[gl];
+            coord += 0.5f * (d * d);
+        } else if (k == C + 3) {
+            const float d = v - l.lw[gl];
+            coord += 0.5f * (d * d);
+        } else {
+            obj += sigmoid_ce(v, 1.0f);
         }
     }
 #pragma unroll
@@ -442,8 +573,9 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     }
 }
 
-// One launch for both branches: the last B * pos_blocks workgroups take the
-// positive branch (short, latency-bound: they fill in behind the negative ones).
+// One launch for both branches: the first B * pos_blocks workgroups take the positive
+// branch (few, each a chain of dependent memory round trips: started first, they run
+// beside the compute-bound negative branch instead of after it).
 static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
 template <bool EXACT_MAX, bool GRAD>
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
@@ -452,9 +584,10 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
     __shared__ float s_val[kLossNegThreads / 64];
     __shared__ int s_idx[kLossNegThreads / 64];
     __shared__ float s_part[kLossNegThreads / 64][3];
-    const uint32_t nneg = (uint32_t)p.B * (uint32_t)p.blocks_per_img;
-    if (blockIdx.x < nneg) loss_neg_block<EXACT_MAX, GRAD>(p, blockIdx.x, s_raw, s_val, s_idx);
-    else loss_pos_block(p, blockIdx.x - nneg, s_val, s_idx, s_part);
+    __shared__ PosLds s_pos;
+    const uint32_t npos = (uint32_t)p.B * (uint32_t)p.pos_blocks;
+    if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
+    else loss_neg_block<EXACT_MAX, GRAD>(p, blockIdx.x - npos, s_raw, s_val, s_idx);
 }
 
 // ---------------------------------------------------------------- finalize
@@ -545,7 +678,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossPa
 // then all threads store the rows' K floats as one contiguous, coalesced run.  Bound: HBM write.
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossParams p)
 {
-    __shared__ float s_g[kLossNegThreads];
+    __shared__ float s_g[kLossNegRows];
     __shared__ float s_val[kLossNegThreads / 64];
     __shared__ int s_idx[kLossNegThreads / 64];
     const int tid = threadIdx.x;
@@ -556,24 +689,26 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossPa
     for (int i = 1; i < YH_MAX_SCALES; ++i)
         if (i < p.S && r >= p.sc[i].blk_begin) s = i;
     const LossScale &sc = p.sc[s];
-    const uint32_t row0 = (r - sc.blk_begin) * kLossNegThreads;
-    const uint32_t row = row0 + tid;
+    const uint32_t row0 = (r - sc.blk_begin) * kLossNegRows;
     const int C = p.C, K = p.K;
-    float g = 0.0f;
-    const bool in_range = row < sc.rows_img;
-    float obj = 0.0f;
-    int counted = 0;
-    if (in_range) {
-        obj = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
-        counted = p.noobj_mask[(long long)b * p.N + sc.row_base + row];
+    float obj[kLossBoxes];
+    int counted[kLossBoxes];
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) {
+        const uint32_t row = row0 + (uint32_t)(i * kLossNegThreads + tid);
+        obj[i] = 0.0f; counted[i] = 0;
+        if (row < sc.rows_img) {
+            obj[i] = sc.head[((long long)b * sc.rows_img + row) * K + C + 4];
+            counted[i] = p.noobj_mask[(long long)b * p.N + sc.row_base + row];
+        }
     }
     const int G = block_gt_count(p.gt + (long long)b * p.pad * 5, p.pad, s_val, s_idx, kLossNegThreads);
     float scale = p.w_noobj * p.grad_w[b];
     if (p.normalize) scale = scale / (float)G;
-    if (counted) g = sigmoidf(obj) * scale;
-    s_g[tid] = g;
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) s_g[i * kLossNegThreads + tid] = counted[i] ? sigmoidf(obj[i]) * scale : 0.0f;
     __syncthreads();
-    const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegThreads ? sc.rows_img - row0 : (uint32_t)kLossNegThreads;
+    const uint32_t nrows = sc.rows_img - row0 < (uint32_t)kLossNegRows ? sc.rows_img - row0 : (uint32_t)kLossNegRows;
     float *dst = sc.grad + ((long long)b * sc.rows_img + row0) * K;
     const uint32_t total = nrows * (uint32_t)K;
     const uint32_t objk = (uint32_t)(C + 4);
@@ -603,35 +738,32 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossPa
 }
 
 // Adds the assigned rows' terms (atomically: several GT rows may share a box).  Runs after
-// k_loss_grad_fill on the same stream.  One wavefront per GT row.
-__device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t block, float *s_val, int *s_idx)
+// k_loss_grad_fill on the same stream.  Same two phases as the forward's positive branch.
+__device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t block, float *s_val, int *s_idx, PosLds &l)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int b = (int)(block / (uint32_t)p.pos_blocks);
     const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
     const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
-    const int g = blk * kLossPosGtPerBlock + wave;
-    if (g >= G) return;
+    const int n = pos_assign(p, b, blk, G, l, true);
     const int C = p.C, K = p.K;
-    const GtAssign a = assign_gt(p, gt + g * 5);
-    if (!a.inside) return;
-    const LossScale &sc = p.sc[a.s];
+    const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;
     float w = p.grad_w[b];
     if (p.normalize) w = w / (float)G;
-    const long long at = (long long)b * sc.rows_img * K + (long long)a.row * K;
-    const float *rowp = sc.head + at;
-    float *grow = sc.grad + at;
-    for (int k = lane; k < K; k += 64) {
+    for (int it = tid; it < n * K; it += kPosThreads) {
+        const int gl = (int)__umulhi((uint32_t)it, magic), k = it - gl * K;
+        const float *rowp = l.rowp[gl];
+        if (!rowp) continue;
         const float v = rowp[k];
         float d;
-        if (k < C) d = p.w_class * (sigmoidf(v) - (k == a.label ? 1.0f : 0.0f));
-        else if (k == C) d = p.w_coord * (sigmoidf(v) - (a.gy - floorf(a.gy)));
-        else if (k == C + 1) d = p.w_coord * (sigmoidf(v) - (a.gx - floorf(a.gx)));
-        else if (k == C + 2) d = p.w_coord * (v - logf(a.gh / a.prior_h));
-        else if (k == C + 3) d = p.w_coord * (v - logf(a.gw / a.prior_w));
+        if (k < C) d = p.w_class * (sigmoidf(v) - (k == l.label[gl] ? 1.0f : 0.0f));
+        else if (k == C) d = p.w_coord * (sigmoidf(v) - l.fy[gl]);
+        else if (k == C + 1) d = p.w_coord * (sigmoidf(v) - l.fx[gl]);
+        else if (k == C + 2) d = p.w_coord * (v - l.lh[gl]);
+        else if (k == C + 3) d = p.w_coord * (v - l.lw[gl]);
         else d = p.w_obj * (sigmoidf(v) - 1.0f);
-        atomicAdd(&grow[k], d * w);
+        atomicAdd(&l.growp[gl][k], d * w);
     }
 }
 
@@ -639,7 +771,8 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams 
 {
     __shared__ float s_val[kPosThreads / 64];
     __shared__ int s_idx[kPosThreads / 64];
-    loss_grad_pos(p, blockIdx.x, s_val, s_idx);
+    __shared__ PosLds s_pos;
+    loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos);
 }
 
 // After the fused forward + gradient-fill pass: the assigned rows' terms, and in one more
@@ -649,8 +782,9 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos_finalize(const Lo
     __shared__ float s_val[kPosThreads / 64];
     __shared__ int s_idx[kPosThreads / 64];
     __shared__ double s_sum[kFinalizeClasses];
+    __shared__ PosLds s_pos;
     if (blockIdx.x + 1u == gridDim.x) loss_finalize<kPosThreads>(p, s_sum);
-    else loss_grad_pos(p, blockIdx.x, s_val, s_idx);
+    else loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos);
 }
 
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(const NmsParams p)
     }
     if (tid == 0) {
         p.img_count[b] = 0;                                   // leaves the counter clean for the next call
-        p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
+        p.status[b] = image_status(found, raw, cap);
     }
     __syncthreads();
     unsigned long long *out = p.seg_keys + (long long)b * cap;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParam
         s_cur[c] = o;
         s_end[c] = o + n;
     }
-    if (sub == 0 && tid == 0) p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
+    if (sub == 0 && tid == 0) p.status[b] = image_status(found, raw, cap);
     __syncthreads();
     const unsigned long long *cand = p.cand + (long long)b * cap;
     for (int i = begin + tid; i < end; i += kBinSliceThreads) atomicAdd(&s_mine[key_class(cand[i])], 1);

@@ -360,7 +360,7 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
     if (tid == 0) {
         p.img_count[b] = 0;                                   // leaves the counter clean for the next call
         // the list keeps at most `cap` of the `raw` entries its producers counted
-        p.status[b] = (found > cap || raw > cap) ? YH_STATUS_CANDIDATE_OVERFLOW : 0;
+        p.status[b] = image_status(found, raw, cap);
     }
     const unsigned long long *sorted;
     const float4 *sbox;

@@ -76,10 +76,19 @@ __device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float
     uint32_t gy = __umulhi(cell, sc.magic_w);
     uint32_t gx = cell - gy * sc.grid_w;
     if (gx >= sc.grid_w) { gx -= sc.grid_w; ++gy; }
+    // The prior of a per-lane index: a uniform walk over the table (scalar reads of the parameter block
+    // and a select each) instead of an indexed read, which would be a vector load from memory with a
+    // full round trip in the middle of the decode.
+    float ph = sc.prior_hw[0][0], pw = sc.prior_hw[0][1];
+    for (int k = 1; k < P; ++k) {
+        const float kh = sc.prior_hw[k][0], kw = sc.prior_hw[k][1];
+        ph = pi == (uint32_t)k ? kh : ph;
+        pw = pi == (uint32_t)k ? kw : pw;
+    }
     const float by = ((float)gy + 0.5f) + decode_sigmoid(ty);
     const float bx = ((float)gx + 0.5f) + decode_sigmoid(tx);
-    const float bh = sc.prior_hw[pi][0] + decode_exp(th);
-    const float bw = sc.prior_hw[pi][1] + decode_exp(tw);
+    const float bh = ph + decode_exp(th);
+    const float bw = pw + decode_exp(tw);
     const float m = sc.mult;
     float4 o;
     o.x = (by - bh / 2.0f) * m;

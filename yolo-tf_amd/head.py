@@ -60,14 +60,25 @@ class Detections:
             return False
         return bool(int((self.status & _abi.YH_STATUS_CANDIDATE_OVERFLOW).max().item()))
 
+    def needed_candidates(self):
+        """Synchronises; the largest candidate count an overflowed image reported (a multiple
+        of 256, from the status words), 0 when no image overflowed."""
+        if self.status.numel() == 0:
+            return 0
+        st = self.status[(self.status & _abi.YH_STATUS_CANDIDATE_OVERFLOW) != 0]
+        if st.numel() == 0:
+            return 0
+        return int((st >> _abi.YH_STATUS_COUNT_SHIFT).max().item()) * 256
+
     def resolved(self):
-        """Synchronises; while the candidate capacity overflows, reruns with a
-        16x larger one (up to the worst case N*C) and returns the final result."""
+        """Synchronises; while the candidate capacity overflows, reruns with one sized by the
+        counts the overflowed images reported (up to the worst case N*C) and returns the
+        final result."""
         r = self
         while r.overflowed():
             if r._rerun is None:
                 raise RuntimeError('candidate capacity overflow; raise max_candidates')
-            r = r._rerun()
+            r = r._rerun(r.needed_candidates())
         return r
 
     def per_image(self):
@@ -166,6 +177,14 @@ class DetectionHead:
         full = N * self.num_classes
         return int(min(full, self._grown.get(N, self.SMALL_CAPACITY)))
 
+    @staticmethod
+    def _grow(cap, needed, full):
+        """The capacity of a second call after an overflow: a quarter above what the fullest
+        image reported (rounded up to 2048: whole slices of the class binning), at least twice
+        the old one, at most every (box, class) pair."""
+        want = max(2 * cap, (needed + needed // 4 + 2047) // 2048 * 2048)
+        return int(min(full, want))
+
     def _alloc_outputs(self, B, max_boxes, dev, want_class_candidates):
         C = self.num_classes
         cap = C * max_boxes
@@ -234,8 +253,8 @@ class DetectionHead:
         if cap < full:
             auto = _auto or max_candidates is None
 
-            def rerun():
-                grown = min(full, cap * 16)
+            def rerun(needed):
+                grown = self._grow(cap, needed, full)
                 if auto:                                    # remembered for later calls on this geometry
                     self._grown[N] = max(grown, self._grown.get(N, 0))
                 return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown,
@@ -270,8 +289,8 @@ class DetectionHead:
         if cap < full:
             auto = _auto or max_candidates is None
 
-            def rerun():
-                grown = min(full, cap * 16)
+            def rerun(needed):
+                grown = self._grow(cap, needed, full)
                 if auto:
                     self._grown[N] = max(grown, self._grown.get(N, 0))
                 return self.nms(boxes, conf, score_threshold, iou_threshold, max_boxes, grown,

@@ -44,7 +44,7 @@ def make_config(grids, priors, box_mult, gt_rate, num_classes):
 class Detections:
     """Device-resident result of DetectionHead.detect / .nms for a batch."""
 
-    def __init__(self, count, scores, boxes, class_id, index, class_candidates, status, rerun):
+    def __init__(self, count, scores, boxes, class_id, index, class_candidates, status, rerun, stream=None):
         self.count = count                  # [B] int32
         self.scores = scores                # [B, C*max_boxes] float32, first count[b] valid
         self.boxes = boxes                  # [B, C*max_boxes, 4] float32 (y1, x1, y2, x2)
@@ -53,9 +53,17 @@ class Detections:
         self.class_candidates = class_candidates   # [B, C] int32 or None
         self.status = status                # [B] int32 per-image device status words
         self._rerun = rerun
+        self._stream = stream               # the stream the producing launch was enqueued on, when not the current one
+
+    def synchronize(self):
+        """Waits for the launch that writes these tensors when it went to a stream of its own
+        (a pipeline's or a lane's); reading them from the current stream before would race."""
+        if self._stream is not None:
+            self._stream.synchronize()
 
     def overflowed(self):
         """Synchronises and reports whether an image exceeded max_candidates."""
+        self.synchronize()
         if self.status.numel() == 0:
             return False
         return bool(int((self.status & _abi.YH_STATUS_CANDIDATE_OVERFLOW).max().item()))
@@ -63,6 +71,7 @@ class Detections:
     def needed_candidates(self):
         """Synchronises; the largest candidate count an overflowed image reported (a multiple
         of 256, from the status words), 0 when no image overflowed."""
+        self.synchronize()
         if self.status.numel() == 0:
             return 0
         st = self.status[(self.status & _abi.YH_STATUS_CANDIDATE_OVERFLOW) != 0]
@@ -259,7 +268,7 @@ class DetectionHead:
                     self._grown[N] = max(grown, self._grown.get(N, 0))
                 return self.detect(heads, score_threshold, iou_threshold, max_boxes, grown,
                                    want_class_candidates, _auto=auto, stream=stream)
-        return Detections(*outputs, rerun)
+        return Detections(*outputs, rerun, stream=stream)
 
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
             want_class_candidates=False, _auto=False):
@@ -511,7 +520,7 @@ class DetectPipeline:
         else:
             with torch.cuda.device(dev):
                 _abi.check(lib.yh_detect_pipelined(*args))
-        done = Detections(*prev[3], None)
+        done = Detections(*prev[3], None, stream=self.stream)
         self._prev = mine
         self._i += 1
         return done
@@ -546,7 +555,7 @@ class DetectPipeline:
                           prev[3] if prev is not None else None, dev, stream_events)
         with torch.cuda.device(dev):
             _abi.check(lib.yh_detect_pipelined(*args))
-        done = Detections(*prev[3], None) if prev is not None else None
+        done = Detections(*prev[3], None, stream=self.stream) if prev is not None else None
         self._prev = (cfg, B, ws, self._outputs[slot], dev, cap)
         if prev is not None and stream_events is None:
             self._steady[slot] = (tuple(h.shape for h in heads), dev, cap, prev[2], prev[3], args, arr,
@@ -564,7 +573,7 @@ class DetectPipeline:
         with torch.cuda.device(dev):
             _abi.check(lib.yh_detect_pipelined(*args))
         self._prev = None
-        return Detections(*outputs, None)
+        return Detections(*outputs, None, stream=self.stream)
 
 
 class DetectLanes:

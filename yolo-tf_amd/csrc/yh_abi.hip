@@ -212,14 +212,15 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
             for (int s = 0; s < p.S; ++s) upi += ((uint64_t)p.sc[s].rows_img + 64 * steps - 1) / (64 * steps);
             return (upi + waves - 1) / waves * waves;
         };
-        // Default: the fewest steps per unit (down to two) with which the launch's streaming workgroups
-        // are resident at once, two per compute unit: a unit of up to four steps asks for all its
-        // objectness logits at the start, and no workgroup waits for a slot before it can ask.
+        // Default: the fewest steps per unit (down to two) with which the whole launch is resident at once,
+        // two workgroups per compute unit, counting the select stage's workgroup per image that rides in
+        // a pipelined launch (it holds its slot for about 12 us): a unit of up to four steps asks for all
+        // its objectness logits at the start, and no workgroup waits for a slot before it can ask.
         uint64_t steps = (uint64_t)knob(kTuneRowSteps, 0);
         if (steps == 0) {
             steps = 4;
             for (uint64_t cand = 2; cand <= 16; ++cand)
-                if ((uint64_t)B * (units_per_image(cand) / waves) <= kRowsResidentGroups) { steps = cand; break; }
+                if ((uint64_t)B * (units_per_image(cand) / waves + 1) <= kRowsResidentGroups) { steps = cand; break; }
         }
         while (units_per_image(steps) > (uint64_t)yh::kMaxUnitsPerImage) ++steps;
         p.tile_rows = 64;

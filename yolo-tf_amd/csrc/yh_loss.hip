@@ -295,12 +295,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         // guarantee (no product can overflow); otherwise, and for a pair inside the margin or
         // with a zero union, the exact walk decides.
         const float thr = p.ignore_thr;
-        const bool fast = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f && dims_ok;
+        const bool fast_all = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f;   // the same for the whole workgroup
         const float eps = 0x1p-20f * fmaxf(1.0f, thr);
         float e_max[kLossBoxes], h_min[kLossBoxes];
 #pragma unroll
-        for (int i = 0; i < kLossBoxes; ++i) { e_max[i] = -INFINITY; h_min[i] = fast ? INFINITY : -INFINITY; }
-        const int pairs = fast ? (G + 1) >> 1 : 0;
+        for (int i = 0; i < kLossBoxes; ++i) { e_max[i] = -INFINITY; h_min[i] = (fast_all && dims_ok) ? INFINITY : -INFINITY; }
+        // a lane whose own box is out of bounds runs along (the trip count stays uniform) and is walked exactly afterwards:
+        // its h_min starts below zero and v_min / v_max never let a NaN in
+        const int pairs = fast_all ? (G + 1) >> 1 : 0;
         const f2 c_hi = {-(thr + eps), -(thr + eps)}, c_lo = {-(thr - eps), -(thr - eps)};
         auto pair_step = [&](int j) {
             const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'

@@ -25,12 +25,13 @@ for i in range(10):
 torch.cuda.synchronize()
 tr = np.zeros((1 << 14, 8), np.uint64)
 assert lib.yh_trace_loss_read(tr.ctypes.data, tr.nbytes, 0) == 0
-tr = tr[tr[:, 7] > 0]
+tr_all_mask = tr[:, 7] > 0
+tr = tr[tr_all_mask]
 t = tr[:, :6].astype(np.float64) / 100.0
 t -= t[:, 0].min()
 def q(x):
     return 'min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' % (x.min(), *np.percentile(x, [10, 50, 90]), x.max())
-print('%d negative-branch workgroups (wavefront 0 of each)' % len(t))
+print('%d negative-branch wavefronts' % len(t))
 for name, x in (('start', t[:, 0]), ('GT staged at', t[:, 1]), ('GT converted (barrier) at', t[:, 2]), ('IoU loop done at', t[:, 3]),
                 ('cross-entropy done at', t[:, 4]), ('end', t[:, 5]), ('staging', t[:, 1] - t[:, 0]), ('conversion', t[:, 2] - t[:, 1]),
                 ('setup + IoU loop', t[:, 3] - t[:, 2]), ('cross-entropy', t[:, 4] - t[:, 3]), ('reduce + write', t[:, 5] - t[:, 4])):
@@ -38,3 +39,25 @@ for name, x in (('start', t[:, 0]), ('GT staged at', t[:, 1]), ('GT converted (b
 for s in range(3):
     m = tr[:, 6] == s
     print('  scale %d: %4d workgroups, IoU loop %s' % (s, m.sum(), q((t[:, 3] - t[:, 2])[m])))
+
+# where the wavefronts ran: HW_ID bits 4-5 SIMD, 8-11 CU, 12 shader array, 13-15 shader engine; bits 40+ the XCD
+hw = ((tr[:, 7] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
+xcd = ((tr[:, 7] >> np.uint64(40)) & np.uint64(15)).astype(np.int64)
+simd = (xcd << 12) | (((hw >> 8) & 0xff) << 4) | ((hw >> 4) & 3)
+ids, inv, cnt = np.unique(simd, return_inverse=True, return_counts=True)
+print('  %d distinct SIMDs; negative-branch wavefronts per SIMD: %s' % (len(ids), {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))}))
+loop = t[:, 3] - t[:, 2]
+for c in sorted(set(cnt)):
+    m = cnt[inv] == c
+    print('    SIMDs with %d: loop %s' % (c, q(loop[m])))
+    print('                   done at %s' % q(t[:, 3][m]))
+late = np.argsort(t[:, 5])[-8:]
+for i in late:
+    print('    late: wavefront %5d scale %d xcd %d hw %08x  start %5.2f setup %5.2f loop %5.2f end %5.2f' % (i, tr[i, 6], xcd[i], hw[i], t[i, 0], t[i, 2], t[i, 3], t[i, 5]))
+# which workgroups share a CU (the scalar data cache is per CU): launch order -> placement
+cuid = (xcd << 8) | ((hw >> 8) & 0xff)
+blk = np.nonzero(tr_all_mask)[0] // 4
+for c in list(np.unique(cuid))[:3] + list(np.unique(cuid))[100:102]:
+    m = cuid == c
+    print('    CU %04x: workgroups %s' % (c, sorted(set(blk[m].tolist()))))
+print('    XCD of workgroups 0..15: %s' % [int(xcd[blk == i][0]) for i in range(16)])

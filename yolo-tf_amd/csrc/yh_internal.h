@@ -36,19 +36,30 @@ __device__ inline float key_score(unsigned long long k)
 }
 
 // ---- arithmetic shared by every kernel (fp32, no contraction) -----------
-// The loss uses the library exp / log and IEEE division (sigmoidf, sigmoid_ce).  The decode
-// (YOLOv3.py:338-345: sigmoid of the class, objectness and centre logits, exp of the size logits)
-// uses the hardware's exp2 and reciprocal, one ulp each: exp(x) = exp2(x * log2(e)) carries the
-// rounding of the product into the exponent, a relative error below 2^-23 * (2 + 1.45 |x|), i.e.
-// 2e-6 at |x| = 10 and 8e-6 at the largest finite results, inside the 1e-5 the path is held to.
-// Every decode kernel uses these two functions, so the staged and the fused paths agree bit for bit.
+// Both the decode (YOLOv3.py:338-345: sigmoid of the class, objectness and centre logits, exp of the
+// size logits) and the loss (sigmoid cross-entropy and its derivative) use the hardware's exp2, log2
+// and reciprocal, one ulp each: exp(x) = exp2(x * log2(e)) carries the rounding of the product into
+// the exponent, a relative error below 2^-23 * (2 + 1.45 |x|), i.e. 2e-6 at |x| = 10 and 8e-6 at
+// the largest finite results, inside the 1e-5 the path is held to.  Every decode kernel uses these
+// two functions, so the staged and the fused paths agree bit for bit.
 __device__ __forceinline__ float decode_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float decode_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + decode_exp(-x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
+__device__ __forceinline__ float sigmoidf(float x) { return decode_sigmoid(x); }
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|)).  With t = exp(-|x|)
+// in (0, 1]: below 1/16 the series of log1p (its sixth term is under 2e-8 of the sum); from 1/16 on
+// log(u) * t / (u - 1) with u = 1 + t rounded, which takes the rounding of the sum back out (u - 1
+// is exact).  A few ulp in either branch, against the library's 147 instructions some 25.
 __device__ __forceinline__ float sigmoid_ce(float x, float z)
 {
-    return (fmaxf(x, 0.0f) - x * z) + log1pf(expf(-fabsf(x)));
+    const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896340736f);
+    const float u = 1.0f + t, d = u - 1.0f;
+    const float wide = (__builtin_amdgcn_logf(u) * 0.693147180559945309417f) * (t * __builtin_amdgcn_rcpf(d));
+    float poly = __builtin_fmaf(t, 0.2f, -0.25f);
+    poly = __builtin_fmaf(t, poly, 0.333333333333333333f);
+    poly = __builtin_fmaf(t, poly, -0.5f);
+    poly = __builtin_fmaf(t, poly, 1.0f);
+    const float l = t < 0.0625f ? t * poly : wide;
+    return (fmaxf(x, 0.0f) - x * z) + l;
 }
 
 // ---- streaming pass (decode / threshold / compaction) --------------------
@@ -185,6 +196,8 @@ struct LossScale {
     uint32_t blk_begin;     // first negative-branch block of this scale inside an image
     float gt_rate;
     float *grad;            // backward: d/d(head), same shape as head
+    uint32_t occ_begin;     // first word of this scale's cell-occupancy bitmap inside an image's bitmaps
+    uint32_t magic_p, magic_w;   // row / P and cell / W by multiply-high; 0: divide (divisor 1, or rows too many for the magic)
     float prior_hw[YH_MAX_PRIORS][2];
 };
 
@@ -206,11 +219,18 @@ struct LossParams {
     double *reduce_pair;          // [2] at the start of the workspace: fp64 sum of the per-image losses, image count
     uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
     const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
+    // written by k_loss_prep, read by k_loss_main (null in the backward-only launches)
+    float *prep_pairs;            // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side
+    int32_t *prep_meta;           // [B][S][2]: ground-truth rows of the image; 1 if every corner and area is below 2^40 in magnitude
+    uint32_t *prep_occ;           // [B][occ_words_img]: per scale, one bit per cell holding a ground-truth centre
+    int32_t pair_cap;             // pairs per (image, scale) in prep_pairs: even, >= ceil(pad / 2)
+    int32_t occ_words_img;
+    int32_t cu_slots;             // compute units of the device (0: keep the launch order of the negative-branch blocks)
     LossScale sc[YH_MAX_SCALES];
 };
 
 hipError_t launch_loss(const LossParams &p, hipStream_t st);
-size_t loss_lds_bytes(int pad, int occ_words);      // dynamic LDS of the loss kernel: GT block + occupancy bitmap
+size_t loss_lds_bytes(int occ_words);               // dynamic LDS of k_loss_prep: the occupancy bitmap of one scale
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;

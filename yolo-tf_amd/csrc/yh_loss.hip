@@ -14,7 +14,7 @@
 namespace yh {
 
 #ifdef YH_ROWS_TRACE
-// Measurement build only (tools/trace_loss.py): per-workgroup timestamps of the negative branch.
+// Measurement build only (tools/trace_loss.py): per-wavefront timestamps of the negative branch.
 constexpr int kLossTraceGroups = 1 << 14, kLossTraceWords = 8;
 __device__ unsigned long long g_loss_trace[kLossTraceGroups * kLossTraceWords];
 #define YH_LT(var) do { var = wall_clock64(); } while (0)
@@ -74,43 +74,73 @@ __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx
     return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
 }
 
-// The image's ground-truth block [pad][5] staged in LDS with coalesced loads (one memory
-// round trip for everything the workgroup needs from it), and _get_normlized_gn's row count
-// (block_gt_count's result) taken from there.
-__device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int *s_idx, int nthreads)
+// ---------------------------------------------------------------- preparation
+// B * S small workgroups ahead of the main launch: one turns an image's ground-truth rows
+// into what every negative-branch workgroup of (image, scale) needs, once instead of once per
+// workgroup: _get_normlized_gn's row count, the corners and areas in the scale's grid units
+// (YOLOv3.py:246-257 operand order) laid out two rows side by side for the packed loop, the
+// bounds flag of the division-free predicate, and the bitmap of cells holding a GT centre.
+// The table is padded with copies of the last row up to a multiple of four rows (a turn of
+// the main loop takes four): a maximum over the rows does not notice a repeated row.
+constexpr int kPrepThreads = 128;
+
+__global__ __launch_bounds__(kPrepThreads) void k_loss_prep(const LossParams p)
 {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ float s_val[kPrepThreads / 64];
+    __shared__ int s_idx[kPrepThreads / 64];
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_raw);
     const int tid = threadIdx.x;
-    for (int i = tid; i < pad * 5; i += nthreads) s_gt[i] = gt[i];
-    __syncthreads();
-    float bv = INFINITY;
-    int bi = 0x7fffffff;
-    for (int j = tid; j < pad; j += nthreads) {
-        const float v = s_gt[j * 5];
-        if (v < bv) { bv = v; bi = j; }
-    }
+    const int b = (int)(blockIdx.x / (uint32_t)p.S), s = (int)blockIdx.x - b * p.S;
+    int H = 0, W = 0;
+    uint32_t occ_begin = 0;
+    float rate = 1.0f;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const float ov = __shfl_xor(bv, d, 64);
-        const int oi = __shfl_xor(bi, d, 64);
-        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int i = 0; i < YH_MAX_SCALES; ++i)
+        if (i == s) { H = p.sc[i].H; W = p.sc[i].W; occ_begin = p.sc[i].occ_begin; rate = p.sc[i].gt_rate; }
+    const int occ_words = (H * W + 31) >> 5;
+    for (int i = tid; i < occ_words; i += kPrepThreads) s_occ[i] = 0u;
+    const float *gt = p.gt + (long long)b * p.pad * 5;
+    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPrepThreads);     // its barriers cover s_occ too
+    float *tab = p.prep_pairs + ((size_t)b * p.S + s) * (size_t)p.pair_cap * kPairStride;
+    const int slots = ((G + 3) >> 2) << 2;
+    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
+    for (int g = tid; g < slots; g += kPrepThreads) {
+        const float *row = gt + (g < G ? g : G - 1) * 5;
+        const float gy = row[0] / rate, gx = row[1] / rate;
+        const float gh = row[2] / rate, gw = row[3] / rate;
+        const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
+        const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
+        const float area = (y2 - y1) * (x2 - x1);
+        const float v[5] = {y1, x1, y2, x2, area};
+        float *slot = tab + (g >> 1) * kPairStride + (g & 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            slot[2 * k] = v[k];
+            in_bounds &= fabsf(v[k]) < kLossFastBound ? 1 : 0;
+        }
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (g < G && cy >= 0 && cy < H && cx >= 0 && cx < W) {
+            const int cell = cy * W + cx;
+            atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
+        }
     }
-    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
-    __syncthreads();
-    float fv = s_val[0];
-    int fi = s_idx[0];
-    for (int w = 1; w < nthreads / 64; ++w) {
-        const float ov = s_val[w];
-        const int oi = s_idx[w];
-        if (ov < fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
+    in_bounds = __syncthreads_and(in_bounds);
+    uint32_t *occ = p.prep_occ + (size_t)b * p.occ_words_img + occ_begin;
+    for (int i = tid; i < occ_words; i += kPrepThreads) occ[i] = s_occ[i];
+    if (tid == 0) {
+        p.prep_meta[((size_t)b * p.S + s) * 2] = G;
+        p.prep_meta[((size_t)b * p.S + s) * 2 + 1] = in_bounds;
     }
-    __syncthreads();
-    return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
 }
 
 // ---------------------------------------------------------------- negative
 // B * blocks_per_img workgroups; one owns kLossNegRows consecutive box rows of one scale
-// of one image, kLossBoxes per lane.  s_raw: 5 * pad floats (GT corners + area at this scale)
-// followed by the cell-occupancy bitmap of the scale.
+// of one image, kLossBoxes per lane.  What it needs of the ground truth comes from k_loss_prep's
+// table through the scalar data path: the table is the same for every lane, so its values are
+// operands in scalar registers and the loop issues no LDS or vector-memory reads at all (read
+// from LDS, the same values cost as much return bandwidth as 64 different ones, and that
+// bandwidth, not the arithmetic, then set the loop's pace).
 //
 // EXACT_MAX = false (the caller does not ask for the IoU maxima): only the
 // predicate "some IoU exceeds the threshold" is needed, and it is decided
@@ -122,19 +152,60 @@ __device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int
 //
 // GRAD = true: the workgroup also writes its rows of the gradient tensor (what
 // k_loss_grad_fill writes: zeros, and the no-object term in the objectness column).  The
-// zeros are 16-byte stores spread over the IoU loop, one every other step, so the memory
-// system drains them while the loop keeps the vector units busy (the loop is compute-bound,
-// the fill is write-bound); lanes that skip the loop catch up after it; the objectness
-// column follows once the mask is known, behind the barrier that orders it after the zeros.
-template <bool EXACT_MAX, bool GRAD>
-__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw,
-                                               float *s_val, int *s_idx)
-{
-    // [ceil(pad/2)][12]: two ground-truth rows side by side, y1 y1' x1 x1' y2 y2' x2 x2' area area' - -
-    float *s_pair = reinterpret_cast<float *>(s_raw);
-    float *s_gt = s_pair + (size_t)((p.pad + 1) >> 1) * kPairStride;    // [pad][5]: y1 x1 y2 x2 area
-    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
+// zeros are 16-byte stores spread over the IoU loop, so the memory system drains them while
+// the loop keeps the vector units busy (the loop is compute-bound, the fill is write-bound);
+// lanes that skip the loop catch up after it; the objectness column follows once the mask is
+// known, behind the barrier that orders it after the zeros.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const f4v const_f4_t;      // read through the scalar data path
+typedef __attribute__((address_space(4))) const float const_float_t;
+typedef __attribute__((address_space(4))) const int32_t const_int_t;
 
+typedef float f8v __attribute__((ext_vector_type(8)));
+
+// Four ground-truth rows (two pairs) of the prepared table in scalar registers.
+struct Turn { f8v lohi0; f2 ar0; f8v lohi1; f2 ar1; };
+
+// Starts the four scalar loads of a turn without waiting for them.  Every register they write is one
+// the loop reads later (no padding is loaded): a register with no reader would be free for the
+// compiler to reuse while its load is still in flight.
+__device__ __forceinline__ void turn_issue(Turn &t, const const_float_t *src)
+{
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\t"
+                 "s_load_dwordx2 %1, %4, 0x20\n\t"
+                 "s_load_dwordx8 %2, %4, 0x30\n\t"
+                 "s_load_dwordx2 %3, %4, 0x50"
+                 : "=&s"(t.lohi0), "=&s"(t.ar0), "=&s"(t.lohi1), "=&s"(t.ar1) : "s"(src));
+}
+// Waits for every scalar load in flight; the values of t may be used after it and not before.
+__device__ __forceinline__ void turn_wait(Turn &t)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t.lohi0), "+s"(t.ar0), "+s"(t.lohi1), "+s"(t.ar1));
+}
+
+// A value that is the same in every lane, kept in a scalar register.
+__device__ __forceinline__ float uniform_value(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// v_min_f32 / v_max_f32 with the first operand in a scalar register
+__device__ __forceinline__ float vmin_s(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax_s(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
+template <bool EXACT_MAX, bool GRAD>
+__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, float *s_val)
+{
     unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
     (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
     YH_LT(lt0);
@@ -146,47 +217,18 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     for (int i = 1; i < YH_MAX_SCALES; ++i)
         if (i < p.S && r >= p.sc[i].blk_begin) s = i;
     const LossScale &sc = p.sc[s];
-    const int C = p.C, K = p.K, P = p.P, H = sc.H, W = sc.W;
-    const float *gt = p.gt + (long long)b * p.pad * 5;
-
-    const int occ_words = (H * W + 31) >> 5;
-    for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
-    const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
+    const int C = p.C, K = p.K, P = p.P, W = sc.W;
+    const size_t bs = (size_t)b * p.S + s;
+    const const_int_t *meta = (const const_int_t *)p.prep_meta + bs * 2;
+    const int G = meta[0];
+    const bool gt_in_bounds = meta[1] != 0;
+    const const_float_t *tab = (const const_float_t *)p.prep_pairs + bs * (size_t)p.pair_cap * kPairStride;
+    const const_int_t *occ = (const const_int_t *)p.prep_occ + (size_t)b * p.occ_words_img + sc.occ_begin;
     YH_LT(lt1);
-    const float rate = sc.gt_rate;
-    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
-    for (int g = tid; g < G; g += kLossNegThreads) {           // row g is rewritten in place by its only reader
-        const float gy = s_gt[g * 5 + 0] / rate, gx = s_gt[g * 5 + 1] / rate;
-        const float gh = s_gt[g * 5 + 2] / rate, gw = s_gt[g * 5 + 3] / rate;
-        const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
-        const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
-        s_gt[g * 5 + 0] = y1; s_gt[g * 5 + 1] = x1; s_gt[g * 5 + 2] = y2; s_gt[g * 5 + 3] = x2;
-        const float area = (y2 - y1) * (x2 - x1);
-        s_gt[g * 5 + 4] = area;
-        if (!EXACT_MAX) {
-            const float v[5] = {y1, x1, y2, x2, area};
-            float *slot = s_pair + (g >> 1) * kPairStride + (g & 1);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                slot[2 * k] = v[k];
-                if (g == G - 1 && (g & 1) == 0) slot[2 * k + 1] = v[k];    // odd count: the last row twice
-                in_bounds &= fabsf(v[k]) < kLossFastBound ? 1 : 0;
-            }
-        }
-        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
-        if (cy >= 0 && cy < H && cx >= 0 && cx < W) {
-            const int cell = cy * W + cx;
-            atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
-        }
-    }
-    const bool gt_in_bounds = __syncthreads_and(in_bounds) != 0;
-    YH_LT(lt2);
 
-    // The objectness logits are asked for here, after the ground-truth round trip (memory loads
-    // return in issue order: an earlier request would hold that round trip back), and are not
-    // needed before the IoU loop below has run: the loop hides their latency.
-    // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart: every
-    // ground-truth pair read from LDS serves all of them.
+    // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart.  The
+    // objectness logits are not needed before the IoU loop below has run: the loop hides
+    // their latency.
     const uint32_t row0 = (r - sc.blk_begin) * kLossNegRows;
     uint32_t row[kLossBoxes];
     bool in_range[kLossBoxes];
@@ -237,14 +279,27 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         by1[i] = bx1[i] = by2[i] = bx2[i] = aarea[i] = 0.0f;
         live[i] = false;
         if (in_range[i]) {
-            const uint32_t cell = row[i] / (uint32_t)P;
+            const uint32_t cell = sc.magic_p ? __umulhi(row[i], sc.magic_p) : row[i] / (uint32_t)P;
             const uint32_t pi = row[i] - cell * (uint32_t)P;
-            const uint32_t cy = cell / (uint32_t)W, cx = cell - cy * (uint32_t)W;
-            live[i] = !((s_occ[cell >> 5] >> (cell & 31)) & 1u);
+            const uint32_t cy = sc.magic_w ? __umulhi(cell, sc.magic_w) : cell / (uint32_t)W;
+            const uint32_t cx = cell - cy * (uint32_t)W;
+            // the wavefront's 64 rows lie in at most 64 consecutive cells: three words of the bitmap, the same
+            // for every lane (scalar reads, which do not queue behind the objectness loads), and a select
+            const uint32_t wrow = row0 + (uint32_t)(i * kLossNegThreads + (tid & ~63));
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((sc.magic_p ? __umulhi(wrow, sc.magic_p) : wrow / (uint32_t)P) >> 5));
+            const uint32_t o0 = (uint32_t)occ[w0], o1 = (uint32_t)occ[w0 + 1], o2 = (uint32_t)occ[w0 + 2];
+            const uint32_t wsel = (cell >> 5) - w0;
+            const uint32_t oword = wsel == 0u ? o0 : (wsel == 1u ? o1 : o2);
+            live[i] = !((oword >> (cell & 31)) & 1u);
             const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
-            float ah = 0.0f, aw = 0.0f;                       // uniform walk: scalar reads of the parameter block
-            for (int q = 0; q < P; ++q)
-                if (pi == (uint32_t)q) { ah = sc.prior_hw[q][0]; aw = sc.prior_hw[q][1]; }
+            // uniform walk over the priors: scalar reads of the parameter block and selects.  (Written as
+            // plain selects of loads, the compiler turns the walk into one load at a per-lane address: a
+            // vector load, whose wait also waits for the objectness loads issued above.)
+            float ah = 0.0f, aw = 0.0f;
+            for (int q = 0; q < P; ++q) {
+                const float ph = uniform_value(sc.prior_hw[q][0]), pw = uniform_value(sc.prior_hw[q][1]);
+                if (pi == (uint32_t)q) { ah = ph; aw = pw; }
+            }
             const float ly = ay - ah / 2.0f, lx = ax - aw / 2.0f;
             const float uy = ay + ah / 2.0f, ux = ax + aw / 2.0f;
             by1[i] = ly - uy / 2.0f; bx1[i] = lx - ux / 2.0f;
@@ -254,23 +309,39 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             any_live = any_live || live[i];
         }
     }
+    YH_LT(lt2);
 
     float m[kLossBoxes];
     bool counted[kLossBoxes];                                   // the box enters the no-object sum
 #pragma unroll
     for (int i = 0; i < kLossBoxes; ++i) { m[i] = __builtin_nanf(""); counted[i] = false; }
     // the exact walk of one box: IoU maximum (NaN if any IoU is NaN), intersection NOT clamped at zero (YOLOv3.py:286)
+    // (the table's copies of the last row change neither the maximum nor the NaN flag)
     auto exact_max = [&](int i) {
         float mx = -INFINITY;
         bool any_nan = false;
-        for (int g = 0; g < G; ++g) {
-            const float gy1 = s_gt[g * 5 + 0], gx1 = s_gt[g * 5 + 1];
-            const float gy2 = s_gt[g * 5 + 2], gx2 = s_gt[g * 5 + 3];
-            const float garea = s_gt[g * 5 + 4];
-            const float inter = (vmin(gy2, by2[i]) - vmax(gy1, by1[i])) * (vmin(gx2, bx2[i]) - vmax(gx1, bx1[i]));
+        auto one = [&](float gy1, float gx1, float gy2, float gx2, float garea) {
+            const float inter = (vmin_s(gy2, by2[i]) - vmax_s(gy1, by1[i])) * (vmin_s(gx2, bx2[i]) - vmax_s(gx1, bx1[i]));
             const float iou = inter / ((aarea[i] + garea) - inter);
             if (iou != iou) any_nan = true;
             else if (iou > mx) mx = iou;
+        };
+        auto four = [&](const Turn &t) {
+            one(t.lohi0.s0, t.lohi0.s2, t.lohi0.s4, t.lohi0.s6, t.ar0.x);
+            one(t.lohi0.s1, t.lohi0.s3, t.lohi0.s5, t.lohi0.s7, t.ar0.y);
+            one(t.lohi1.s0, t.lohi1.s2, t.lohi1.s4, t.lohi1.s6, t.ar1.x);
+            one(t.lohi1.s1, t.lohi1.s3, t.lohi1.s5, t.lohi1.s7, t.ar1.y);
+        };
+        const int xturns = (G + 3) >> 2, xlast = xturns - 1;
+        Turn xa, xb;
+        if (xturns > 0) { turn_issue(xa, tab); turn_wait(xa); }
+        for (int t = 0; t < xturns; t += 2) {
+            turn_issue(xb, tab + (t + 1 < xlast ? t + 1 : xlast) * (2 * kPairStride));
+            four(xa);
+            turn_wait(xb);
+            turn_issue(xa, tab + (t + 2 < xlast ? t + 2 : xlast) * (2 * kPairStride));
+            if (t + 1 < xturns) four(xb);
+            turn_wait(xa);
         }
         return any_nan ? __builtin_nanf("") : mx;
     };
@@ -282,61 +353,96 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                 counted[i] = m[i] <= p.ignore_thr;
             }
         }
-    } else if (any_live) {
-        // Division-free pass, two ground-truth rows per step in packed arithmetic.  With the
-        // margin eps = 2^-20 * max(1, thr):
+    } else if (__any(any_live)) {
+        // Division-free pass, two ground-truth rows per step in packed arithmetic, two steps (four
+        // rows) per turn.  With the margin eps = 2^-20 * max(1, thr):
         //   a = inter - (thr + eps) * uni,  e = uni * a:   e > 0  implies  RN(inter / uni) > thr,
         //   b = inter - (thr - eps) * uni,  f = -uni * b:  f > 0  implies  RN(inter / uni) < thr
         // for either sign of the union (a product with uni keeps or flips the inequality exactly as
         // the division by uni does; one rounding in a and b, none that could change the sign of e
         // or f short of an underflow to zero, and a zero decides nothing).  e is folded into a
-        // running maximum (some e > 0: masked), max(e, f) into a running minimum (every pair
-        // decided).  That bookkeeping needs NaN-free values, which the bounds on the operands
-        // guarantee (no product can overflow); otherwise, and for a pair inside the margin or
-        // with a zero union, the exact walk decides.
+        // running maximum (some e > 0: masked).  A turn in which some lane has a row with neither
+        // e > 0 nor f > 0 (inside the margin, or a zero union) settles its four rows with the
+        // division for those lanes there and then: rare, and no second walk afterwards.  The
+        // bookkeeping needs NaN-free values, which the bounds on the operands guarantee (no product
+        // can overflow); a wavefront with an operand out of bounds takes the exact walk.
         const float thr = p.ignore_thr;
-        const bool fast_all = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f;   // the same for the whole workgroup
-        const float eps = 0x1p-20f * fmaxf(1.0f, thr);
-        float e_max[kLossBoxes], h_min[kLossBoxes];
+        const bool fast = gt_in_bounds && thr >= 0.0f && thr < 0x1p20f && __all(dims_ok);   // the same for the whole wavefront
+        if (fast) {
+            const float eps = 0x1p-20f * fmaxf(1.0f, thr);
+            float e_max[kLossBoxes], h_turn[kLossBoxes];
+            bool masked_exact[kLossBoxes];
 #pragma unroll
-        for (int i = 0; i < kLossBoxes; ++i) { e_max[i] = -INFINITY; h_min[i] = (fast_all && dims_ok) ? INFINITY : -INFINITY; }
-        // a lane whose own box is out of bounds runs along (the trip count stays uniform) and is walked exactly afterwards:
-        // its h_min starts below zero and v_min / v_max never let a NaN in
-        const int pairs = fast_all ? (G + 1) >> 1 : 0;
-        const f2 c_hi = {-(thr + eps), -(thr + eps)}, c_lo = {-(thr - eps), -(thr - eps)};
-        auto pair_step = [&](int j) {
-            const float4 lo = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride);      // y1 y1' x1 x1'
-            const float4 hi = *reinterpret_cast<const float4 *>(s_pair + j * kPairStride + 4);  // y2 y2' x2 x2'
-            const float2 ar = *reinterpret_cast<const float2 *>(s_pair + j * kPairStride + 8);
+            for (int i = 0; i < kLossBoxes; ++i) { e_max[i] = -INFINITY; h_turn[i] = INFINITY; masked_exact[i] = false; }
+            const int turns = (G + 3) >> 2;
+            const f2 c_hi = {-(thr + eps), -(thr + eps)}, c_lo = {-(thr - eps), -(thr - eps)};
+            auto pair_step = [&](const f8v lh, const f2 ar, const bool first) {     // y1 y1' x1 x1' y2 y2' x2 x2' / area area'
+#pragma unroll
+                for (int i = 0; i < kLossBoxes; ++i) {
+                    const f2 dy = f2{vmin_s(lh.s4, by2[i]), vmin_s(lh.s5, by2[i])} - f2{vmax_s(lh.s0, by1[i]), vmax_s(lh.s1, by1[i])};
+                    const f2 dx = f2{vmin_s(lh.s6, bx2[i]), vmin_s(lh.s7, bx2[i])} - f2{vmax_s(lh.s2, bx1[i]), vmax_s(lh.s3, bx1[i])};
+                    const f2 inter = dy * dx;
+                    const f2 uni = (f2{aarea[i], aarea[i]} + ar) - inter;
+                    const f2 a = __builtin_elementwise_fma(c_hi, uni, inter);
+                    const f2 b2 = __builtin_elementwise_fma(c_lo, uni, inter);
+                    const f2 e = uni * a, f = -uni * b2;
+                    e_max[i] = fmaxf(e_max[i], fmaxf(e.x, e.y));
+                    const float hx = fmaxf(e.x, f.x), hy = fmaxf(e.y, f.y);
+                    h_turn[i] = first ? fminf(hx, hy) : fminf(h_turn[i], fminf(hx, hy));
+                }
+            };
+            auto one_exact = [&](int i, float gy1, float gx1, float gy2, float gx2, float garea) {
+                const float inter = (vmin_s(gy2, by2[i]) - vmax_s(gy1, by1[i])) * (vmin_s(gx2, bx2[i]) - vmax_s(gx1, bx1[i]));
+                const float iou = inter / ((aarea[i] + garea) - inter);
+                return (iou != iou) || iou > thr;
+            };
+            auto turn_steps = [&](const Turn &t) {
+                pair_step(t.lohi0, t.ar0, true);
+                pair_step(t.lohi1, t.ar1, false);
+                bool undecided = false;
+#pragma unroll
+                for (int i = 0; i < kLossBoxes; ++i) undecided = undecided || !(h_turn[i] > 0.0f);
+                if (__any(undecided)) {
+#pragma unroll
+                    for (int i = 0; i < kLossBoxes; ++i) {
+                        if (!(h_turn[i] > 0.0f)) {
+                            const bool m0 = one_exact(i, t.lohi0.s0, t.lohi0.s2, t.lohi0.s4, t.lohi0.s6, t.ar0.x);
+                            const bool m1 = one_exact(i, t.lohi0.s1, t.lohi0.s3, t.lohi0.s5, t.lohi0.s7, t.ar0.y);
+                            const bool m2 = one_exact(i, t.lohi1.s0, t.lohi1.s2, t.lohi1.s4, t.lohi1.s6, t.ar1.x);
+                            const bool m3 = one_exact(i, t.lohi1.s1, t.lohi1.s3, t.lohi1.s5, t.lohi1.s7, t.ar1.y);
+                            masked_exact[i] = masked_exact[i] || m0 || m1 || m2 || m3;
+                        }
+                    }
+                }
+            };
+            // Two register sets take turns: the scalar loads of the next turn's rows are in flight while this
+            // turn computes.  Issue and wait are written out (the compiler, left to itself, issues a turn's
+            // loads at the top of that turn and waits for them at once); between the two the set being
+            // loaded is not touched.
+            Turn ta, tb;
+            const int last = turns - 1;
+            if (turns > 0) { turn_issue(ta, tab); turn_wait(ta); }
+            for (int t = 0; t < turns; t += 2) {
+                turn_issue(tb, tab + (t + 1 < last ? t + 1 : last) * (2 * kPairStride));
+                if (GRAD) fill_some();
+                turn_steps(ta);
+                turn_wait(tb);
+                turn_issue(ta, tab + (t + 2 < last ? t + 2 : last) * (2 * kPairStride));
+                if (t + 1 < turns) {
+                    if (GRAD) fill_some();
+                    turn_steps(tb);
+                }
+                turn_wait(ta);
+            }
+#pragma unroll
+            for (int i = 0; i < kLossBoxes; ++i) counted[i] = live[i] && !(e_max[i] > 0.0f || masked_exact[i]);
+        } else {
 #pragma unroll
             for (int i = 0; i < kLossBoxes; ++i) {
-                const f2 dy = f2{vmin(hi.x, by2[i]), vmin(hi.y, by2[i])} - f2{vmax(lo.x, by1[i]), vmax(lo.y, by1[i])};
-                const f2 dx = f2{vmin(hi.z, bx2[i]), vmin(hi.w, bx2[i])} - f2{vmax(lo.z, bx1[i]), vmax(lo.w, bx1[i])};
-                const f2 inter = dy * dx;
-                const f2 uni = (f2{aarea[i], aarea[i]} + f2{ar.x, ar.y}) - inter;
-                const f2 a = __builtin_elementwise_fma(c_hi, uni, inter);
-                const f2 b2 = __builtin_elementwise_fma(c_lo, uni, inter);
-                const f2 e = uni * a, f = -uni * b2;
-                e_max[i] = fmaxf(e_max[i], fmaxf(e.x, e.y));
-                h_min[i] = fminf(h_min[i], fminf(fmaxf(e.x, f.x), fmaxf(e.y, f.y)));
-            }
-        };
-        int j = 0;
-        for (; j + 1 < pairs; j += 2) {                        // two steps per turn: the second step's LDS reads travel
-            if (GRAD) fill_some();                             //  while the first step computes
-            pair_step(j);
-            pair_step(j + 1);
-        }
-        if (j < pairs) pair_step(j);
-#pragma unroll
-        for (int i = 0; i < kLossBoxes; ++i) {
-            if (live[i]) {
-                bool masked = e_max[i] > 0.0f;
-                if (!(h_min[i] > 0.0f)) {                      // rare: the exact walk decides
+                if (live[i]) {
                     const float mx = exact_max(i);
-                    masked = (mx != mx) || mx > thr;
+                    counted[i] = !((mx != mx) || mx > thr);
                 }
-                counted[i] = !masked;
             }
         }
     }
@@ -375,9 +481,12 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     }
 #ifdef YH_ROWS_TRACE
     YH_LT(lt5);
-    if ((tid & 63) == 0 && block < (uint32_t)kLossTraceGroups && (tid >> 6) < 1) {
-        unsigned long long *tr = g_loss_trace + (size_t)block * kLossTraceWords;
-        tr[0] = lt0; tr[1] = lt1; tr[2] = lt2; tr[3] = lt3; tr[4] = lt4; tr[5] = lt5; tr[6] = (unsigned long long)s; tr[7] = 1;
+    if ((tid & 63) == 0 && block * (kLossNegThreads / 64) + (tid >> 6) < (uint32_t)kLossTraceGroups) {
+        unsigned long long *tr = g_loss_trace + ((size_t)block * (kLossNegThreads / 64) + (tid >> 6)) * kLossTraceWords;
+        tr[0] = lt0; tr[1] = lt1; tr[2] = lt2; tr[3] = lt3; tr[4] = lt4; tr[5] = lt5; tr[6] = (unsigned long long)s;
+        // where it ran: HW_ID (wave, SIMD, CU, shader array, shader engine) and the XCD
+        tr[7] = 1ull | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) |
+                ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 40);
     }
 #endif
 }
@@ -544,21 +653,15 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
         const float *rowp = l.rowp[gl];
         if (!rowp) continue;
         const float v = rowp[k];
-        if (k < C) {
-            cls += sigmoid_ce(v, k == l.label[gl] ? 1.0f : 0.0f);
-        } else if (k == C) {
-            coord += sigmoid_ce(v, l.fy[gl]);
-        } else if (k == C + 1) {
-            coord += sigmoid_ce(v, l.fx[gl]);
-        } else if (k == C + 2) {
-            const float d = v - l.lh[gl];
-            coord += 0.5f * (d * d);
-        } else if (k == C + 3) {
-            const float d = v - l.lw[gl];
-            coord += 0.5f * (d * d);
-        } else {
-            obj += sigmoid_ce(v, 1.0f);
-        }
+        // one cross-entropy and one squared error per item, the term picked by selects: the branches of
+        // a per-channel if-chain would each run the cross-entropy code for the whole wavefront
+        const float z = k < C ? (k == l.label[gl] ? 1.0f : 0.0f) : (k == C ? l.fy[gl] : (k == C + 1 ? l.fx[gl] : 1.0f));
+        const float ce = sigmoid_ce(v, z);
+        const float dv = v - (k == C + 2 ? l.lh[gl] : l.lw[gl]);
+        const float term = (k == C + 2 || k == C + 3) ? 0.5f * (dv * dv) : ce;
+        if (k < C) cls += term;
+        else if (k < C + 4) coord += term;
+        else obj += term;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -575,6 +678,20 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     }
 }
 
+// While a launch fits the device at once, workgroup q lands on compute unit q mod n (round-robin
+// over the XCDs and their CUs): the workgroups sharing a CU are q, q + n, q + 2n, ...  This maps
+// the launch ids q0 .. q1-1 of the negative branch onto blocks so that those get consecutive
+// blocks (same image, same scale): one ground-truth table per CU in its scalar data cache instead
+// of five or six tables taking turns in it.  A bijection for any n; n = 0 keeps the launch order.
+__device__ __forceinline__ uint32_t cu_major_block(uint32_t q, uint32_t q0, uint32_t q1, uint32_t n)
+{
+    if (n == 0u) return q - q0;
+    auto below = [&](uint32_t x, uint32_t c) { const uint32_t m = x % n; return (x / n) * c + (m < c ? m : c); };   // ids in [0, x) with a residue below c
+    auto same = [&](uint32_t x, uint32_t c) { return x / n + (x % n > c ? 1u : 0u); };                              // ids in [0, x) with residue c
+    const uint32_t c = q % n;
+    return (below(q1, c) - below(q0, c)) + (same(q, c) - same(q0, c));
+}
+
 // One launch for both branches: the first B * pos_blocks workgroups take the positive
 // branch (few, each a chain of dependent memory round trips: started first, they run
 // beside the compute-bound negative branch instead of after it).
@@ -582,14 +699,13 @@ static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
 template <bool EXACT_MAX, bool GRAD>
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
 {
-    extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ float s_val[kLossNegThreads / 64];
     __shared__ int s_idx[kLossNegThreads / 64];
     __shared__ float s_part[kLossNegThreads / 64][3];
     __shared__ PosLds s_pos;
     const uint32_t npos = (uint32_t)p.B * (uint32_t)p.pos_blocks;
     if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
-    else loss_neg_block<EXACT_MAX, GRAD>(p, blockIdx.x - npos, s_raw, s_val, s_idx);
+    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_val);
 }
 
 // ---------------------------------------------------------------- finalize
@@ -758,13 +874,10 @@ __device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t bloc
         const float *rowp = l.rowp[gl];
         if (!rowp) continue;
         const float v = rowp[k];
-        float d;
-        if (k < C) d = p.w_class * (sigmoidf(v) - (k == l.label[gl] ? 1.0f : 0.0f));
-        else if (k == C) d = p.w_coord * (sigmoidf(v) - l.fy[gl]);
-        else if (k == C + 1) d = p.w_coord * (sigmoidf(v) - l.fx[gl]);
-        else if (k == C + 2) d = p.w_coord * (v - l.lh[gl]);
-        else if (k == C + 3) d = p.w_coord * (v - l.lw[gl]);
-        else d = p.w_obj * (sigmoidf(v) - 1.0f);
+        const float z = k < C ? (k == l.label[gl] ? 1.0f : 0.0f) : (k == C ? l.fy[gl] : (k == C + 1 ? l.fx[gl] : 1.0f));
+        const float tgt = k == C + 2 ? l.lh[gl] : l.lw[gl];
+        const float diff = (k == C + 2 || k == C + 3) ? v - tgt : sigmoidf(v) - z;
+        const float d = (k < C ? p.w_class : (k < C + 4 ? p.w_coord : p.w_obj)) * diff;
         atomicAdd(&l.growp[gl][k], d * w);
     }
 }
@@ -799,10 +912,9 @@ hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
     return hipGetLastError();
 }
 
-size_t loss_lds_bytes(int pad, int occ_words)
+size_t loss_lds_bytes(int occ_words)
 {
-    return (size_t)((pad + 1) / 2) * kPairStride * sizeof(float) + (size_t)pad * 5 * sizeof(float) +
-           (size_t)occ_words * sizeof(uint32_t);
+    return (size_t)occ_words * sizeof(uint32_t);
 }
 
 hipError_t launch_loss(const LossParams &p, hipStream_t stm)
@@ -813,14 +925,17 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
         if (w > occ_words) occ_words = w;
     }
-    const size_t lds = loss_lds_bytes(p.pad, occ_words);
+    const size_t lds = loss_lds_bytes(occ_words);
+    hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(k_loss_prep), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss_prep, dim3((uint32_t)p.B * (uint32_t)p.S), dim3(kPrepThreads), lds, stm, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
     const bool grad = p.grad_w != nullptr;                     // forward and gradient in one pass over the rows
     void (*kernel)(const LossParams) = p.iou_max ? (grad ? k_loss_main<true, true> : k_loss_main<true, false>)
                                                  : (grad ? k_loss_main<false, true> : k_loss_main<false, false>);
-    hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(kernel), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), lds, stm, p);
+    hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), 0, stm, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (grad)

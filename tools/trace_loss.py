@@ -25,10 +25,12 @@ for i in range(10):
 torch.cuda.synchronize()
 tr = np.zeros((1 << 14, 8), np.uint64)
 assert lib.yh_trace_loss_read(tr.ctypes.data, tr.nbytes, 0) == 0
-tr_all_mask = tr[:, 7] > 0
+tr_all_mask = (tr[:, 7] > 0) & ((tr[:, 6] & np.uint64(255)) != 255)
+pos = tr[(tr[:, 7] > 0) & ((tr[:, 6] & np.uint64(255)) == 255)]
+t_first = min(int(tr[tr[:, 7] > 0][:, 0].min()), int(pos[:, 0].min()))
 tr = tr[tr_all_mask]
 t = tr[:, :6].astype(np.float64) / 100.0
-t -= t[:, 0].min()
+t -= t_first / 100.0
 def q(x):
     return 'min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' % (x.min(), *np.percentile(x, [10, 50, 90]), x.max())
 print('%d negative-branch wavefronts' % len(t))
@@ -36,6 +38,9 @@ for name, x in (('start', t[:, 0]), ('GT staged at', t[:, 1]), ('GT converted (b
                 ('cross-entropy done at', t[:, 4]), ('end', t[:, 5]), ('staging', t[:, 1] - t[:, 0]), ('conversion', t[:, 2] - t[:, 1]),
                 ('setup + IoU loop', t[:, 3] - t[:, 2]), ('cross-entropy', t[:, 4] - t[:, 3]), ('reduce + write', t[:, 5] - t[:, 4])):
     print('  %-28s %s' % (name, q(x)))
+slow = (tr[:, 6] >> np.uint64(8)).astype(np.int64)
+tr[:, 6] &= np.uint64(255)
+print('  turns on the exact path: %d wavefronts with any, %d turns in all, most in one wavefront %d' % ((slow > 0).sum(), slow.sum(), slow.max()))
 for s in range(3):
     m = tr[:, 6] == s
     print('  scale %d: %4d workgroups, IoU loop %s' % (s, m.sum(), q((t[:, 3] - t[:, 2])[m])))
@@ -53,7 +58,7 @@ for c in sorted(set(cnt)):
     print('                   done at %s' % q(t[:, 3][m]))
 late = np.argsort(t[:, 5])[-8:]
 for i in late:
-    print('    late: wavefront %5d scale %d xcd %d hw %08x  start %5.2f setup %5.2f loop %5.2f end %5.2f' % (i, tr[i, 6], xcd[i], hw[i], t[i, 0], t[i, 2], t[i, 3], t[i, 5]))
+    print('    late: wavefront %5d scale %d xcd %d hw %08x  start %5.2f setup %5.2f loop %5.2f end %5.2f  exact turns %d' % (i, tr[i, 6], xcd[i], hw[i], t[i, 0], t[i, 2], t[i, 3], t[i, 5], slow[i]))
 # which workgroups share a CU (the scalar data cache is per CU): launch order -> placement
 cuid = (xcd << 8) | ((hw >> 8) & 0xff)
 blk = np.nonzero(tr_all_mask)[0] // 4
@@ -61,3 +66,15 @@ for c in list(np.unique(cuid))[:3] + list(np.unique(cuid))[100:102]:
     m = cuid == c
     print('    CU %04x: workgroups %s' % (c, sorted(set(blk[m].tolist()))))
 print('    XCD of workgroups 0..15: %s' % [int(xcd[blk == i][0]) for i in range(16)])
+
+# the positive branch's workgroups and the CUs of the late negative ones
+pt = pos[:, [0, 5]].astype(np.float64) / 100.0 - t_first / 100.0
+print('  %d positive-branch workgroups: start %s' % (len(pt), q(pt[:, 0])))
+print('  %s end   %s' % (' ' * 30, q(pt[:, 1])))
+phw = ((pos[:, 7] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
+pcu = ((((pos[:, 7] >> np.uint64(40)) & np.uint64(15)).astype(np.int64)) << 8) | ((phw >> 8) & 0xff)
+for i in late[-8::4]:
+    c = cuid[i]
+    m = cuid == c
+    print('    CU %04x of late wavefront %d: negative workgroups %s end %s; positive workgroups end %s' % (
+        c, i, sorted(set(blk[m].tolist())), np.round(sorted(set(t[:, 5][m].tolist()))[-3:], 2), np.round(pt[:, 1][pcu == c], 2)))

@@ -225,6 +225,7 @@ struct LossParams {
     uint32_t *prep_occ;           // [B][occ_words_img]: per scale, one bit per cell holding a ground-truth centre
     int32_t pair_cap;             // pairs per (image, scale) in prep_pairs: even, >= ceil(pad / 2)
     int32_t occ_words_img;
+    uint32_t *done_count;         // workgroups of the main launch that have finished (zeroed by k_loss_prep): the last one finalizes
     int32_t cu_slots;             // compute units of the device (0: keep the launch order of the negative-branch blocks)
     LossScale sc[YH_MAX_SCALES];
 };
@@ -234,7 +235,7 @@ size_t loss_lds_bytes(int occ_words);               // dynamic LDS of k_loss_pre
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;
-constexpr int kLossBoxes = 1;            // box rows per lane of the negative branch
+constexpr int kLossBoxes = 2;            // box rows per lane of the negative branch
 constexpr int kLossNegRows = kLossNegThreads * kLossBoxes;   // box rows per workgroup
 constexpr int kLossPosGtPerBlock = 16;  // ground-truth rows per workgroup of the positive branch
 

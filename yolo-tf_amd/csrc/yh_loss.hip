@@ -43,6 +43,18 @@ __device__ __forceinline__ float vmax(float a, float b)
     return r;
 }
 
+// Partial sums travel between workgroups of one launch (the last one to finish combines them)
+// without fences: a store and a load that go to device-coherent memory themselves (the L2 of
+// another XCD is not looked up or left with a stale line), and the writer waits for its stores
+// to be acknowledged before it takes its ticket.  A release / acquire fence pair would do the
+// same by writing back and invalidating the whole L2 in every workgroup, which costs more than
+// the loss kernel itself.
+template <typename T>
+__device__ __forceinline__ void publish(T *ptr, T v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T observe(const T *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // _get_normlized_gn's slice (YOLOv3.py:437): the first index of the minimum of
 // column 0 of gt [pad][5].  Block-wide; result broadcast through *out.
 __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx, int nthreads)
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_loss_prep(const LossParams p)
     in_bounds = __syncthreads_and(in_bounds);
     uint32_t *occ = p.prep_occ + (size_t)b * p.occ_words_img + occ_begin;
     for (int i = tid; i < occ_words; i += kPrepThreads) occ[i] = s_occ[i];
+    if (blockIdx.x == 0 && tid == 0 && p.done_count) *p.done_count = 0u;
     if (tid == 0) {
         p.prep_meta[((size_t)b * p.S + s) * 2] = G;
         p.prep_meta[((size_t)b * p.S + s) * 2 + 1] = in_bounds;
@@ -208,6 +221,8 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
 {
     unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
     (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
+    unsigned slow_turns = 0;                                    // measurement build: turns that took the exact path
+    (void)slow_turns;
     YH_LT(lt0);
     const int tid = threadIdx.x;
     const int b = block / p.blocks_per_img;
@@ -403,6 +418,9 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
 #pragma unroll
                 for (int i = 0; i < kLossBoxes; ++i) undecided = undecided || !(h_turn[i] > 0.0f);
                 if (__any(undecided)) {
+#ifdef YH_ROWS_TRACE
+                    ++slow_turns;
+#endif
 #pragma unroll
                     for (int i = 0; i < kLossBoxes; ++i) {
                         if (!(h_turn[i] > 0.0f)) {
@@ -477,13 +495,13 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
     if (tid == 0) {
         float acc = s_val[0];
         for (int w = 1; w < kLossNegThreads / 64; ++w) acc += s_val[w];
-        p.neg_partial[(long long)b * p.blocks_per_img + r] = acc;
+        publish(&p.neg_partial[(long long)b * p.blocks_per_img + r], acc);
     }
 #ifdef YH_ROWS_TRACE
     YH_LT(lt5);
     if ((tid & 63) == 0 && block * (kLossNegThreads / 64) + (tid >> 6) < (uint32_t)kLossTraceGroups) {
         unsigned long long *tr = g_loss_trace + ((size_t)block * (kLossNegThreads / 64) + (tid >> 6)) * kLossTraceWords;
-        tr[0] = lt0; tr[1] = lt1; tr[2] = lt2; tr[3] = lt3; tr[4] = lt4; tr[5] = lt5; tr[6] = (unsigned long long)s;
+        tr[0] = lt0; tr[1] = lt1; tr[2] = lt2; tr[3] = lt3; tr[4] = lt4; tr[5] = lt5; tr[6] = (unsigned long long)s | ((unsigned long long)slow_turns << 8);
         // where it ran: HW_ID (wave, SIMD, CU, shader array, shader engine) and the XCD
         tr[7] = 1ull | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) |
                 ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 40);
@@ -643,7 +661,7 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
     const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
-    if (blk == 0 && tid == 0) p.gcount[b] = G;
+    if (blk == 0 && tid == 0) publish(&p.gcount[b], G);
     const int n = pos_assign(p, b, blk, G, l, false);
     const int C = p.C, K = p.K;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;   // item -> row by multiply-high (items < 2^17)
@@ -671,52 +689,23 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     }
     if (lane == 0) { s_part[wave][0] = coord; s_part[wave][1] = cls; s_part[wave][2] = obj; }
     __syncthreads();
-    if (tid < 3) {
-        float acc = s_part[0][tid];
-        for (int w2 = 1; w2 < kPosThreads / 64; ++w2) acc += s_part[w2][tid];
-        p.pos_partial[((long long)b * p.pos_blocks + blk) * 3 + tid] = acc;
+    if (tid == 0) {                                            // the thread that takes the workgroup's ticket writes all of it
+        for (int k = 0; k < 3; ++k) {
+            float acc = s_part[0][k];
+            for (int w2 = 1; w2 < kPosThreads / 64; ++w2) acc += s_part[w2][k];
+            publish(&p.pos_partial[((long long)b * p.pos_blocks + blk) * 3 + k], acc);
+        }
     }
-}
-
-// While a launch fits the device at once, workgroup q lands on compute unit q mod n (round-robin
-// over the XCDs and their CUs): the workgroups sharing a CU are q, q + n, q + 2n, ...  This maps
-// the launch ids q0 .. q1-1 of the negative branch onto blocks so that those get consecutive
-// blocks (same image, same scale): one ground-truth table per CU in its scalar data cache instead
-// of five or six tables taking turns in it.  A bijection for any n; n = 0 keeps the launch order.
-__device__ __forceinline__ uint32_t cu_major_block(uint32_t q, uint32_t q0, uint32_t q1, uint32_t n)
-{
-    if (n == 0u) return q - q0;
-    auto below = [&](uint32_t x, uint32_t c) { const uint32_t m = x % n; return (x / n) * c + (m < c ? m : c); };   // ids in [0, x) with a residue below c
-    auto same = [&](uint32_t x, uint32_t c) { return x / n + (x % n > c ? 1u : 0u); };                              // ids in [0, x) with residue c
-    const uint32_t c = q % n;
-    return (below(q1, c) - below(q0, c)) + (same(q, c) - same(q0, c));
-}
-
-// One launch for both branches: the first B * pos_blocks workgroups take the positive
-// branch (few, each a chain of dependent memory round trips: started first, they run
-// beside the compute-bound negative branch instead of after it).
-static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
-template <bool EXACT_MAX, bool GRAD>
-__global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
-{
-    __shared__ float s_val[kLossNegThreads / 64];
-    __shared__ int s_idx[kLossNegThreads / 64];
-    __shared__ float s_part[kLossNegThreads / 64][3];
-    __shared__ PosLds s_pos;
-    const uint32_t npos = (uint32_t)p.B * (uint32_t)p.pos_blocks;
-    if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
-    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_val);
 }
 
 // ---------------------------------------------------------------- finalize
 // One workgroup: per-image combination (YOLOv3.py:308-310 / YOLOv2.py:172) and
-// the batch sum.  Sixteen lanes per image (64 images at a time with 1024 threads): they
+// the batch sum.  Sixteen lanes per image (16 images at a time with 256 threads): they
 // fetch the image's partial sums together and add them up in double in a fixed tree.  The
 // batch sum is defined over kFinalizeClasses residue classes of the image index (class g
 // adds the losses of images g, g + 64, ... in that order, then the classes are added in
 // order), whatever the workgroup's size: a smaller workgroup keeps several classes per lane
 // group.  The result depends neither on scheduling nor on the workgroup's size.
-constexpr int kFinalizeThreads = 1024;
 constexpr int kFinalizeLanes = 16;
 constexpr int kFinalizeClasses = 64;
 
@@ -739,11 +728,11 @@ __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum
     for (int k = 0; k < kPerGroup; ++k) local[k] = 0.0;
     for (int b = grp, turn = 0; b < p.B; b += kFinalizeGroups, ++turn) {
         double coord = 0.0, cls = 0.0, obj = 0.0, noobj = 0.0;
-        const float gf = p.normalize ? (float)p.gcount[b] : 1.0f;
+        const float gf = p.normalize ? (float)observe(&p.gcount[b]) : 1.0f;
         const float *pp = p.pos_partial + (long long)b * p.pos_blocks * 3;
-        for (int i = gl; i < p.pos_blocks; i += kFinalizeLanes) { coord += pp[i * 3]; cls += pp[i * 3 + 1]; obj += pp[i * 3 + 2]; }
+        for (int i = gl; i < p.pos_blocks; i += kFinalizeLanes) { coord += observe(&pp[i * 3]); cls += observe(&pp[i * 3 + 1]); obj += observe(&pp[i * 3 + 2]); }
         const float *np_ = p.neg_partial + (long long)b * p.blocks_per_img;
-        for (int i = gl; i < p.blocks_per_img; i += kFinalizeLanes) noobj += np_[i];
+        for (int i = gl; i < p.blocks_per_img; i += kFinalizeLanes) noobj += observe(&np_[i]);
         coord = group_sum(coord); cls = group_sum(cls); obj = group_sum(obj); noobj = group_sum(noobj);
         const float fc = (float)coord, fk = (float)cls, fo = (float)obj, fn = (float)noobj;
         float pos = (p.w_coord * fc + p.w_class * fk) + p.w_obj * fo;
@@ -778,10 +767,68 @@ __device__ __forceinline__ void loss_finalize(const LossParams &p, double *s_sum
     }
 }
 
-__global__ __launch_bounds__(kFinalizeThreads) void k_loss_finalize(const LossParams p)
+// While a launch fits the device at once, workgroup q lands on compute unit q mod n (round-robin
+// over the XCDs and their CUs): the workgroups sharing a CU are q, q + n, q + 2n, ...  This maps
+// the launch ids q0 .. q1-1 of the negative branch onto blocks so that those get consecutive
+// blocks (same image, same scale): one ground-truth table per CU in its scalar data cache instead
+// of five or six tables taking turns in it.  A bijection for any n; n = 0 keeps the launch order.
+__device__ __forceinline__ uint32_t cu_major_block(uint32_t q, uint32_t q0, uint32_t q1, uint32_t n)
+{
+    if (n == 0u) return q - q0;
+    auto below = [&](uint32_t x, uint32_t c) { const uint32_t m = x % n; return (x / n) * c + (m < c ? m : c); };   // ids in [0, x) with a residue below c
+    auto same = [&](uint32_t x, uint32_t c) { return x / n + (x % n > c ? 1u : 0u); };                              // ids in [0, x) with residue c
+    const uint32_t c = q % n;
+    return (below(q1, c) - below(q0, c)) + (same(q, c) - same(q0, c));
+}
+
+// One launch for both branches: the first B * pos_blocks workgroups take the positive
+// branch (few, each a chain of dependent memory round trips: started first, they run
+// beside the compute-bound negative branch instead of after it).
+static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
+template <bool EXACT_MAX, bool GRAD>
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
+{
+    __shared__ float s_val[kLossNegThreads / 64];
+    __shared__ int s_idx[kLossNegThreads / 64];
+    __shared__ float s_part[kLossNegThreads / 64][3];
+    __shared__ PosLds s_pos;
+    __shared__ double s_sum[kFinalizeClasses];
+    __shared__ int s_last;
+    const uint32_t npos = (uint32_t)p.B * (uint32_t)p.pos_blocks;
+#ifdef YH_ROWS_TRACE
+    const unsigned long long pt0 = wall_clock64();
+#endif
+    if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
+    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_val);
+#ifdef YH_ROWS_TRACE
+    if (blockIdx.x < npos && threadIdx.x == 0) {                // positive branch: start, end, place, marker 2
+        const size_t at = (size_t)(gridDim.x - npos) * (kLossNegThreads / 64) + blockIdx.x;
+        if (at < (size_t)kLossTraceGroups) {
+            unsigned long long *tr = g_loss_trace + at * kLossTraceWords;
+            tr[0] = pt0; tr[5] = wall_clock64(); tr[6] = 255;
+            tr[7] = 1ull | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) |
+                    ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 40);
+        }
+    }
+#endif
+    if (!GRAD && p.done_count) {
+        // The workgroup that finishes last combines the partial sums (with GRAD the launch that
+        // follows does): every workgroup publishes its sums and takes a ticket; the holder of the
+        // last ticket reads them all.  No workgroup waits for another, and the combination's order
+        // does not depend on who is last.
+        if (threadIdx.x == 0) {                                // thread 0 wrote the workgroup's sums
+            stores_acknowledged();
+            s_last = atomicAdd(p.done_count, 1u) + 1u == gridDim.x ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_last) loss_finalize<kLossNegThreads>(p, s_sum);
+    }
+}
+
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_finalize(const LossParams p)
 {
     __shared__ double s_sum[kFinalizeClasses];
-    loss_finalize<kFinalizeThreads>(p, s_sum);
+    loss_finalize<kLossNegThreads>(p, s_sum);
 }
 
 // ---------------------------------------------------------------- backward
@@ -940,8 +987,8 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
     if (e != hipSuccess) return e;
     if (grad)
         hipLaunchKernelGGL(k_loss_grad_pos_finalize, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks + 1u), dim3(kPosThreads), 0, stm, p);
-    else
-        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kFinalizeThreads), 0, stm, p);
+    else if (!p.done_count)
+        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kLossNegThreads), 0, stm, p);
     return hipGetLastError();
 }
 

@@ -768,7 +768,7 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
     std::memset(&p, 0, sizeof(p));
     p.S = cfg->num_scales; p.B = batch; p.C = cfg->num_classes; p.P = cfg->num_priors;
     p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg); p.pad = pad;
-    uint32_t blk = 0, row_base = 0, occ = 0;
+    uint32_t blk = 0, row_base = 0;
     for (int s = 0; s < p.S; ++s) {
         yh::LossScale &sc = p.sc[s];
         sc.H = cfg->grid_h[s]; sc.W = cfg->grid_w[s];
@@ -777,7 +777,6 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
         sc.blk_begin = blk;
         sc.gt_rate = cfg->gt_rate[s];
         std::memcpy(sc.prior_hw, cfg->prior_hw[s], sizeof(sc.prior_hw));
-        sc.occ_begin = occ;
         // q = umulhi(n, floor(2^32 / d) + 1) equals n / d for every n with n * d < 2^32
         auto magic = [](uint32_t d, uint64_t n_max) -> uint32_t {
             if (d <= 1u || n_max * d >= ((uint64_t)1 << 32)) return 0u;
@@ -787,16 +786,14 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
         sc.magic_w = magic((uint32_t)sc.W, (uint64_t)sc.H * sc.W);
         blk += (sc.rows_img + yh::kLossNegRows - 1) / yh::kLossNegRows;
         row_base += sc.rows_img;
-        occ += (uint32_t)((sc.H * sc.W + 31) >> 5);
     }
-    p.occ_words_img = (int32_t)occ;
     p.pair_cap = 2 * ((pad + 3) / 4);
     p.blocks_per_img = (int32_t)blk;
     p.pos_blocks = (pad + yh::kLossPosGtPerBlock - 1) / yh::kLossPosGtPerBlock;
     if (p.pos_blocks < 1) p.pos_blocks = 1;
 }
 
-struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *prep_pairs; int32_t *prep_meta; uint32_t *prep_occ; uint32_t *done; size_t bytes; };
+struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *pair_tab; size_t bytes; };
 
 static LossWs carve_loss(void *base, const yh::LossParams &p)
 {
@@ -809,17 +806,11 @@ static LossWs carve_loss(void *base, const yh::LossParams &p)
     const size_t o_pos = take((size_t)p.B * p.pos_blocks * 3 * 4);
     const size_t o_g = take((size_t)p.B * 4);
     const size_t o_pp = take((size_t)p.B * p.S * p.pair_cap * 12 * 4);
-    const size_t o_pm = take((size_t)p.B * p.S * 2 * 4);
-    const size_t o_dn = take(4);
-    const size_t o_po = take((size_t)p.B * p.occ_words_img * 4 + 16);   // a wavefront reads three words from its first cell's on
     w.pair = reinterpret_cast<double *>(c + o_pair);
     w.neg = reinterpret_cast<float *>(c + o_neg);
     w.pos = reinterpret_cast<float *>(c + o_pos);
     w.gcount = reinterpret_cast<int32_t *>(c + o_g);
-    w.prep_pairs = reinterpret_cast<float *>(c + o_pp);
-    w.prep_meta = reinterpret_cast<int32_t *>(c + o_pm);
-    w.prep_occ = reinterpret_cast<uint32_t *>(c + o_po);
-    w.done = reinterpret_cast<uint32_t *>(c + o_dn);
+    w.pair_tab = reinterpret_cast<float *>(c + o_pp);
     w.bytes = off;
     return w;
 }
@@ -836,11 +827,11 @@ static int check_loss_sizes(const yh_head_config *cfg, int32_t batch, int32_t pa
         const int w = (cfg->grid_h[s] * cfg->grid_w[s] + 31) >> 5;
         occ_words = w > occ_words ? w : occ_words;
     }
-    // the occupancy bitmap of the largest grid is built in a workgroup's LDS
-    const size_t lds = yh::loss_lds_bytes(occ_words) + 1024;
+    // the ground-truth rows and the occupancy bitmap of the largest grid share a workgroup's LDS
+    const size_t lds = yh::loss_lds_bytes(pad, occ_words) + 2048;
     if (lds > yh::kLdsPerWorkgroupMax)
-        return fail(YH_ERR_LIMIT, "a grid of %d cells needs %zu bytes of LDS, %zu available", occ_words * 32, lds,
-                    yh::kLdsPerWorkgroupMax);
+        return fail(YH_ERR_LIMIT, "pad %d with a grid of %d cells needs %zu bytes of LDS, %zu available", pad,
+                    occ_words * 32, lds, yh::kLdsPerWorkgroupMax);
     return YH_OK;
 }
 
@@ -895,12 +886,14 @@ static int loss_forward(const yh_head_config *cfg, const float *const *heads, co
     p.normalize = normalize_by_num_gt ? 1 : 0;
     p.gt = ground_truth;
     p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount; p.reduce_pair = w.pair;
-    p.prep_pairs = w.prep_pairs; p.prep_meta = w.prep_meta; p.prep_occ = w.prep_occ;
+    p.pair_tab = w.pair_tab;
     p.cu_slots = compute_units();
     // The last workgroup of the main launch finalizes while the launch is small enough for the tickets
     // (one atomic per workgroup on one address) to cost less than a launch of their own; measured at
     // 896 workgroups: 0.9 us in favour of the tickets, at 1568: 8 us against them.
-    p.done_count = (int64_t)batch * (p.pos_blocks + p.blocks_per_img) <= 1024 ? w.done : nullptr;
+    static std::atomic<uint32_t> next_ticket{0};
+    p.ticket_slot = (int64_t)batch * (p.pos_blocks + p.blocks_per_img) <= 1024
+                        ? (int32_t)(next_ticket.fetch_add(1, std::memory_order_relaxed) % 4096u) : -1;
     p.loss_per_image = loss_per_image; p.loss_parts = loss_parts; p.iou_max = iou_max; p.loss_sum = loss_sum;
     p.noobj_mask = noobj_mask;
     const hipError_t e = yh::launch_loss(p, static_cast<hipStream_t>(stream));

@@ -196,7 +196,6 @@ struct LossScale {
     uint32_t blk_begin;     // first negative-branch block of this scale inside an image
     float gt_rate;
     float *grad;            // backward: d/d(head), same shape as head
-    uint32_t occ_begin;     // first word of this scale's cell-occupancy bitmap inside an image's bitmaps
     uint32_t magic_p, magic_w;   // row / P and cell / W by multiply-high; 0: divide (divisor 1, or rows too many for the magic)
     float prior_hw[YH_MAX_PRIORS][2];
 };
@@ -219,19 +218,16 @@ struct LossParams {
     double *reduce_pair;          // [2] at the start of the workspace: fp64 sum of the per-image losses, image count
     uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
     const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
-    // written by k_loss_prep, read by k_loss_main (null in the backward-only launches)
-    float *prep_pairs;            // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side
-    int32_t *prep_meta;           // [B][S][2]: ground-truth rows of the image; 1 if every corner and area is below 2^40 in magnitude
-    uint32_t *prep_occ;           // [B][occ_words_img]: per scale, one bit per cell holding a ground-truth centre
-    int32_t pair_cap;             // pairs per (image, scale) in prep_pairs: even, >= ceil(pad / 2)
-    int32_t occ_words_img;
-    uint32_t *done_count;         // workgroups of the main launch that have finished (zeroed by k_loss_prep): the last one finalizes
+    float *pair_tab;              // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side:
+                                  //   written and read back by the negative-branch workgroups of the main launch
+    int32_t pair_cap;             // pairs per (image, scale) in pair_tab: even, >= ceil(pad / 2)
+    int32_t ticket_slot;          // the launch's cell of the library's ticket array; -1: a launch of its own finalizes
     int32_t cu_slots;             // compute units of the device (0: keep the launch order of the negative-branch blocks)
     LossScale sc[YH_MAX_SCALES];
 };
 
 hipError_t launch_loss(const LossParams &p, hipStream_t st);
-size_t loss_lds_bytes(int occ_words);               // dynamic LDS of k_loss_prep: the occupancy bitmap of one scale
+size_t loss_lds_bytes(int pad, int occ_words);      // dynamic LDS of the loss kernel: raw GT rows + occupancy bitmap
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;

@@ -25,6 +25,7 @@ __device__ unsigned long long g_loss_trace[kLossTraceGroups * kLossTraceWords];
 constexpr int kPosThreads = kLossNegThreads;     // the positive branch shares the negative branch's launch
 constexpr int kPairStride = 12;              // floats per pair of ground-truth rows in LDS (16-byte aligned)
 constexpr float kLossFastBound = 0x1p40f;
+constexpr int kLossObjTurn = 4;               // the turn of the IoU loop that asks for the objectness logits (even)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // fminf / fmaxf as the bare instructions (IEEE mode: a NaN operand yields the other one, as
@@ -86,74 +87,59 @@ __device__ int block_gt_count(const float *gt, int pad, float *s_val, int *s_idx
     return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
 }
 
-// ---------------------------------------------------------------- preparation
-// B * S small workgroups ahead of the main launch: one turns an image's ground-truth rows
-// into what every negative-branch workgroup of (image, scale) needs, once instead of once per
-// workgroup: _get_normlized_gn's row count, the corners and areas in the scale's grid units
-// (YOLOv3.py:246-257 operand order) laid out two rows side by side for the packed loop, the
-// bounds flag of the division-free predicate, and the bitmap of cells holding a GT centre.
-// The table is padded with copies of the last row up to a multiple of four rows (a turn of
-// the main loop takes four): a maximum over the rows does not notice a repeated row.
-constexpr int kPrepThreads = 128;
-
-__global__ __launch_bounds__(kPrepThreads) void k_loss_prep(const LossParams p)
+// The image's ground-truth block [pad][5] staged in LDS with coalesced loads (one memory
+// round trip for everything the workgroup needs from it), and _get_normlized_gn's row count
+// (block_gt_count's result) taken from there.
+__device__ int stage_gt(const float *gt, int pad, float *s_gt, float *s_val, int *s_idx, int nthreads)
 {
-    extern __shared__ __align__(16) unsigned char s_raw[];
-    __shared__ float s_val[kPrepThreads / 64];
-    __shared__ int s_idx[kPrepThreads / 64];
-    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_raw);
     const int tid = threadIdx.x;
-    const int b = (int)(blockIdx.x / (uint32_t)p.S), s = (int)blockIdx.x - b * p.S;
-    int H = 0, W = 0;
-    uint32_t occ_begin = 0;
-    float rate = 1.0f;
-#pragma unroll
-    for (int i = 0; i < YH_MAX_SCALES; ++i)
-        if (i == s) { H = p.sc[i].H; W = p.sc[i].W; occ_begin = p.sc[i].occ_begin; rate = p.sc[i].gt_rate; }
-    const int occ_words = (H * W + 31) >> 5;
-    for (int i = tid; i < occ_words; i += kPrepThreads) s_occ[i] = 0u;
-    const float *gt = p.gt + (long long)b * p.pad * 5;
-    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPrepThreads);     // its barriers cover s_occ too
-    float *tab = p.prep_pairs + ((size_t)b * p.S + s) * (size_t)p.pair_cap * kPairStride;
-    const int slots = ((G + 3) >> 2) << 2;
-    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
-    for (int g = tid; g < slots; g += kPrepThreads) {
-        const float *row = gt + (g < G ? g : G - 1) * 5;
-        const float gy = row[0] / rate, gx = row[1] / rate;
-        const float gh = row[2] / rate, gw = row[3] / rate;
-        const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
-        const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
-        const float area = (y2 - y1) * (x2 - x1);
-        const float v[5] = {y1, x1, y2, x2, area};
-        float *slot = tab + (g >> 1) * kPairStride + (g & 1);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            slot[2 * k] = v[k];
-            in_bounds &= fabsf(v[k]) < kLossFastBound ? 1 : 0;
-        }
-        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
-        if (g < G && cy >= 0 && cy < H && cx >= 0 && cx < W) {
-            const int cell = cy * W + cx;
-            atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
-        }
+    for (int i = tid; i < pad * 5; i += nthreads) s_gt[i] = gt[i];
+    __syncthreads();
+    float bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < pad; j += nthreads) {
+        const float v = s_gt[j * 5];
+        if (v < bv) { bv = v; bi = j; }
     }
-    in_bounds = __syncthreads_and(in_bounds);
-    uint32_t *occ = p.prep_occ + (size_t)b * p.occ_words_img + occ_begin;
-    for (int i = tid; i < occ_words; i += kPrepThreads) occ[i] = s_occ[i];
-    if (blockIdx.x == 0 && tid == 0 && p.done_count) *p.done_count = 0u;
-    if (tid == 0) {
-        p.prep_meta[((size_t)b * p.S + s) * 2] = G;
-        p.prep_meta[((size_t)b * p.S + s) * 2 + 1] = in_bounds;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(bv, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    float fv = s_val[0];
+    int fi = s_idx[0];
+    for (int w = 1; w < nthreads / 64; ++w) {
+        const float ov = s_val[w];
+        const int oi = s_idx[w];
+        if (ov < fv || (ov == fv && oi < fi)) { fv = ov; fi = oi; }
+    }
+    __syncthreads();
+    return (pad > 0 && fi != 0x7fffffff) ? fi : 0;
 }
+
+// Tickets of the launches whose last workgroup finalizes: library-owned, so that they are known to be
+// zero (a caller's workspace may hold anything); the finalizing workgroup puts its ticket back to zero.
+constexpr int kLossTickets = 4096;
+__device__ unsigned int g_loss_tickets[kLossTickets];
 
 // ---------------------------------------------------------------- negative
 // B * blocks_per_img workgroups; one owns kLossNegRows consecutive box rows of one scale
-// of one image, kLossBoxes per lane.  What it needs of the ground truth comes from k_loss_prep's
-// table through the scalar data path: the table is the same for every lane, so its values are
-// operands in scalar registers and the loop issues no LDS or vector-memory reads at all (read
-// from LDS, the same values cost as much return bandwidth as 64 different ones, and that
-// bandwidth, not the arithmetic, then set the loop's pace).
+// of one image, kLossBoxes per lane.  Dynamic LDS: the image's raw ground-truth rows
+// [pad][5] and the cell-occupancy bitmap of the scale.
+//
+// The workgroup turns the ground-truth rows into corners and areas in the scale's grid units
+// (YOLOv3.py:246-257 operand order), two rows side by side, padded with copies of the last row
+// up to a multiple of four rows (a maximum over the rows does not notice a repeated row), and
+// writes that table to global memory: every workgroup of (image, scale) writes the same bits to
+// the same table, so no workgroup waits for another, and once its own stores are acknowledged
+// the table it reads back is complete.  It reads it back through the scalar data path: the
+// table is the same for every lane, so its values are operands in scalar registers and the loop
+// issues no LDS or vector-memory reads at all (read from LDS, the same values cost as much
+// return bandwidth as 64 different ones, and that bandwidth, not the arithmetic, then set the
+// loop's pace).
 //
 // EXACT_MAX = false (the caller does not ask for the IoU maxima): only the
 // predicate "some IoU exceeds the threshold" is needed, and it is decided
@@ -217,7 +203,7 @@ __device__ __forceinline__ float vmax_s(float a, float b)
 }
 
 template <bool EXACT_MAX, bool GRAD>
-__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, float *s_val)
+__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw, float *s_val, int *s_idx)
 {
     unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
     (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
@@ -233,17 +219,50 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         if (i < p.S && r >= p.sc[i].blk_begin) s = i;
     const LossScale &sc = p.sc[s];
     const int C = p.C, K = p.K, P = p.P, W = sc.W;
-    const size_t bs = (size_t)b * p.S + s;
-    const const_int_t *meta = (const const_int_t *)p.prep_meta + bs * 2;
-    const int G = meta[0];
-    const bool gt_in_bounds = meta[1] != 0;
-    const const_float_t *tab = (const const_float_t *)p.prep_pairs + bs * (size_t)p.pair_cap * kPairStride;
-    const const_int_t *occ = (const const_int_t *)p.prep_occ + (size_t)b * p.occ_words_img + sc.occ_begin;
+    const int H = sc.H;
+    const float *gt = p.gt + (long long)b * p.pad * 5;
+    float *s_gt = reinterpret_cast<float *>(s_raw);                         // [pad][5]: the raw rows
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
+
+    const int occ_words = (H * W + 31) >> 5;
+    for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
+    const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
     YH_LT(lt1);
+    const size_t bs = (size_t)b * p.S + s;
+    float *tab_w = p.pair_tab + bs * (size_t)p.pair_cap * kPairStride;
+    const const_float_t *tab = (const const_float_t *)tab_w;
+    const float rate = sc.gt_rate;
+    const int slots = ((G + 3) >> 2) << 2;
+    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
+    for (int g = tid; g < slots; g += kLossNegThreads) {
+        const float *row = s_gt + (g < G ? g : G - 1) * 5;
+        const float gy = row[0] / rate, gx = row[1] / rate;
+        const float gh = row[2] / rate, gw = row[3] / rate;
+        const float y1 = gy - gh / 2.0f, x1 = gx - gw / 2.0f;
+        const float y2 = gy + gh / 2.0f, x2 = gx + gw / 2.0f;
+        const float area = (y2 - y1) * (x2 - x1);
+        const float v[5] = {y1, x1, y2, x2, area};
+        float *slot = tab_w + (g >> 1) * kPairStride + (g & 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            slot[2 * k] = v[k];
+            in_bounds &= fabsf(v[k]) < kLossFastBound ? 1 : 0;
+        }
+        const int cy = (int)floorf(gy), cx = (int)floorf(gx);
+        if (g < G && cy >= 0 && cy < H && cx >= 0 && cx < W) {
+            const int cell = cy * W + cx;
+            atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
+        }
+    }
+    stores_acknowledged();                                      // the table is in the L2 the scalar loads below read from
+    const bool gt_in_bounds = __syncthreads_and(in_bounds) != 0;
 
     // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart.  The
-    // objectness logits are not needed before the IoU loop below has run: the loop hides
-    // their latency.
+    // objectness logits are not needed before the IoU loop below has run, and the loop hides
+    // their latency.  They are asked for a few turns into the loop rather than here: the
+    // workgroups of a compute unit start within a microsecond or two of each other, and a table
+    // store of a late one queued behind the objectness loads of an early one in the unit's
+    // memory pipeline (some 40 MB for the whole launch) waited up to 10 us for its acknowledgement.
     const uint32_t row0 = (r - sc.blk_begin) * kLossNegRows;
     uint32_t row[kLossBoxes];
     bool in_range[kLossBoxes];
@@ -253,8 +272,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
         row[i] = row0 + (uint32_t)(i * kLossNegThreads + tid);
         in_range[i] = row[i] < sc.rows_img;
         obj[i] = 0.0f;
-        if (in_range[i]) obj[i] = sc.head[((long long)b * sc.rows_img + row[i]) * K + C + 4];
     }
+    bool obj_asked = false;
+    auto ask_obj = [&]() {
+#pragma unroll
+        for (int i = 0; i < kLossBoxes; ++i)
+            if (in_range[i]) obj[i] = sc.head[((long long)b * sc.rows_img + row[i]) * K + C + 4];
+        obj_asked = true;
+    };
 
     // the workgroup's run of the gradient tensor: `lead` single floats up to 16-byte alignment,
     // nb 16-byte blocks, then fewer than four single floats
@@ -298,14 +323,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             const uint32_t pi = row[i] - cell * (uint32_t)P;
             const uint32_t cy = sc.magic_w ? __umulhi(cell, sc.magic_w) : cell / (uint32_t)W;
             const uint32_t cx = cell - cy * (uint32_t)W;
-            // the wavefront's 64 rows lie in at most 64 consecutive cells: three words of the bitmap, the same
-            // for every lane (scalar reads, which do not queue behind the objectness loads), and a select
-            const uint32_t wrow = row0 + (uint32_t)(i * kLossNegThreads + (tid & ~63));
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((sc.magic_p ? __umulhi(wrow, sc.magic_p) : wrow / (uint32_t)P) >> 5));
-            const uint32_t o0 = (uint32_t)occ[w0], o1 = (uint32_t)occ[w0 + 1], o2 = (uint32_t)occ[w0 + 2];
-            const uint32_t wsel = (cell >> 5) - w0;
-            const uint32_t oword = wsel == 0u ? o0 : (wsel == 1u ? o1 : o2);
-            live[i] = !((oword >> (cell & 31)) & 1u);
+            live[i] = !((s_occ[cell >> 5] >> (cell & 31)) & 1u);
             const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
             // uniform walk over the priors: scalar reads of the parameter block and selects.  (Written as
             // plain selects of loads, the compiler turns the walk into one load at a per-lane address: a
@@ -442,6 +460,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             if (turns > 0) { turn_issue(ta, tab); turn_wait(ta); }
             for (int t = 0; t < turns; t += 2) {
                 turn_issue(tb, tab + (t + 1 < last ? t + 1 : last) * (2 * kPairStride));
+                if (t == kLossObjTurn) ask_obj();
                 if (GRAD) fill_some();
                 turn_steps(ta);
                 turn_wait(tb);
@@ -464,6 +483,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             }
         }
     }
+    if (!obj_asked) ask_obj();
     YH_LT(lt3);
     float contrib = 0.0f;
 #pragma unroll
@@ -788,6 +808,7 @@ static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
 template <bool EXACT_MAX, bool GRAD>
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
 {
+    extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ float s_val[kLossNegThreads / 64];
     __shared__ int s_idx[kLossNegThreads / 64];
     __shared__ float s_part[kLossNegThreads / 64][3];
@@ -799,7 +820,7 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
     const unsigned long long pt0 = wall_clock64();
 #endif
     if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
-    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_val);
+    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_raw, s_val, s_idx);
 #ifdef YH_ROWS_TRACE
     if (blockIdx.x < npos && threadIdx.x == 0) {                // positive branch: start, end, place, marker 2
         const size_t at = (size_t)(gridDim.x - npos) * (kLossNegThreads / 64) + blockIdx.x;
@@ -811,17 +832,20 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
         }
     }
 #endif
-    if (!GRAD && p.done_count) {
+    if (!GRAD && p.ticket_slot >= 0) {
         // The workgroup that finishes last combines the partial sums (with GRAD the launch that
         // follows does): every workgroup publishes its sums and takes a ticket; the holder of the
         // last ticket reads them all.  No workgroup waits for another, and the combination's order
         // does not depend on who is last.
         if (threadIdx.x == 0) {                                // thread 0 wrote the workgroup's sums
             stores_acknowledged();
-            s_last = atomicAdd(p.done_count, 1u) + 1u == gridDim.x ? 1 : 0;
+            s_last = atomicAdd(&g_loss_tickets[p.ticket_slot], 1u) + 1u == gridDim.x ? 1 : 0;
         }
         __syncthreads();
-        if (s_last) loss_finalize<kLossNegThreads>(p, s_sum);
+        if (s_last) {
+            loss_finalize<kLossNegThreads>(p, s_sum);
+            if (threadIdx.x == 0) publish(&g_loss_tickets[p.ticket_slot], 0u);
+        }
     }
 }
 
@@ -959,9 +983,9 @@ hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
     return hipGetLastError();
 }
 
-size_t loss_lds_bytes(int occ_words)
+size_t loss_lds_bytes(int pad, int occ_words)
 {
-    return (size_t)occ_words * sizeof(uint32_t);
+    return (size_t)pad * 5 * sizeof(float) + (size_t)occ_words * sizeof(uint32_t);
 }
 
 hipError_t launch_loss(const LossParams &p, hipStream_t stm)
@@ -972,22 +996,19 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
         if (w > occ_words) occ_words = w;
     }
-    const size_t lds = loss_lds_bytes(occ_words);
-    hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(k_loss_prep), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_loss_prep, dim3((uint32_t)p.B * (uint32_t)p.S), dim3(kPrepThreads), lds, stm, p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    const size_t lds = loss_lds_bytes(p.pad, occ_words);
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
     const bool grad = p.grad_w != nullptr;                     // forward and gradient in one pass over the rows
     void (*kernel)(const LossParams) = p.iou_max ? (grad ? k_loss_main<true, true> : k_loss_main<true, false>)
                                                  : (grad ? k_loss_main<false, true> : k_loss_main<false, false>);
-    hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), 0, stm, p);
+    hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(kernel), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), lds, stm, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (grad)
         hipLaunchKernelGGL(k_loss_grad_pos_finalize, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks + 1u), dim3(kPosThreads), 0, stm, p);
-    else if (!p.done_count)
+    else if (p.ticket_slot < 0)
         hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kLossNegThreads), 0, stm, p);
     return hipGetLastError();
 }

@@ -13,7 +13,7 @@ from yolo_tf_amd import _abi
 dev = torch.device('cuda:0')
 w = bench.WORKLOADS[os.environ.get('AB_WORKLOAD', 'detect416')]
 grids, priors, box_mult, gt_rate = bench.build_head(w)
-B, P, C = w['batch'], len(priors[0]), w['C']
+B, P, C = int(os.environ.get('AB_BATCH', w['batch'])), len(priors[0]), w['C']
 cfg = y.head.make_config(grids, priors, box_mult, gt_rate, C)
 libs = []
 for k, path in enumerate(sys.argv[1:3]):
@@ -21,16 +21,16 @@ for k, path in enumerate(sys.argv[1:3]):
     for name in ('yh_detect_workspace_bytes', 'yh_detect_candidates', 'yh_set_tuning'):
         fn = getattr(lib, name); fn.restype, fn.argtypes = _abi.SIGNATURES[name]
     steps = int(sys.argv[3 + k]) if len(sys.argv) > 3 + k else 0
-    t = _abi.Tuning(row_steps=steps)
+    t = _abi.Tuning(row_steps=steps, stream_blocks=int(os.environ.get('AB_BLOCKS', 0)))
     assert lib.yh_set_tuning(ctypes.byref(t)) == 0
     libs.append((os.path.basename(path) + ('/steps%d' % steps if steps else ''), lib))
-cap, mb = 2048, w['max_boxes']
+cap, mb = int(os.environ.get('AB_CAP', 2048)), w['max_boxes']   # AB_CAP above the select stage's limit: the workgroup-tile variant
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 only = os.environ.get('AB_ONLY_BENCH')
 for label, dist in (('benchmark distribution', {}),) if only else (('benchmark distribution', {}), ('mu -4, no candidates', dict(obj_mean=-4.0, hot_mean=-6.0)),
                     ('mu -2', dict(obj_mean=-2.0, hot_mean=-6.0)), ('mu 0', dict(obj_mean=0.0, hot_mean=-6.0)),
                     ('mu +2', dict(obj_mean=2.0, hot_mean=-6.0)), ('mu +9', dict(obj_mean=9.0, hot_mean=-6.0))):
-    sets = [y.synth.torch_heads(dev, 40 + i, B, grids, P, C, **dist) for i in range(6)]
+    sets = [y.synth.torch_heads(dev, 40 + i, B, grids, P, C, **dict(w['dist'], **dist)) for i in range(6)]
     surv = bench.row_survival(sets[:1], C, w['thr'])
     ptrs = [_abi.pointer_array([h.data_ptr() for h in hs]) for hs in sets]
     res = {}

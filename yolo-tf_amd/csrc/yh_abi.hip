@@ -163,7 +163,7 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 }
 
 // Fills the per-scale block decomposition of the streaming pass.  A workgroup
-// walks tiles of whole rows (<= 20 KiB each) and ends with a latency-bound tail
+// walks tiles of whole rows (<= 24 KiB each) and ends with a latency-bound tail
 // (the atomic that reserves its candidate range), so the launch is
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;

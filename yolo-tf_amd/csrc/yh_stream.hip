@@ -3,7 +3,7 @@
 //
 // The NHWC head of one scale is a row-major matrix [B * rows_img][K], K = C + 5,
 // one row per box.  A workgroup walks tiles of whole rows of one image.  A tile
-// (up to 20 KiB) goes from HBM straight into LDS with LDS-DMA loads
+// (up to 24 KiB) goes from HBM straight into LDS with LDS-DMA loads
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination,
 // no VALU work), issued back to back so that the whole tile is in flight at
 // once; the 16-byte phase of the tile start is absorbed by an aligned window

@@ -125,7 +125,8 @@ template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
 {
     __shared__ __attribute__((aligned(16))) Stage st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wavefront's number, known to be uniform
     if (tid == 0) { st.count = 0; st.nhits = 0; }
 
     int s = 0;
@@ -157,12 +158,16 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         const int wslots = (sh + rows_t * K + 3) >> 2;       // window slots, <= kTileFloats / 4
         long long nd = q_last - q0 + 1;                       // slots of the window that may be read as 16 bytes
         const int ndma = nd < wslots ? (int)(nd < 0 ? 0 : nd) : wslots;
+        // a wavefront's 64 slots per load: the group's first slot is a scalar (the branches below are
+        // scalar branches), the lane's address one 64-bit add away from a pointer computed once per tile
+        const float4 *lane_src = src4 + q0 + lane;
 #pragma unroll
         for (int j = 0; j < kTileFloats / 4 / kThreads; ++j) {
-            const int slot0 = (j * (kThreads / 64) + wave) * 64;
-            if (slot0 < ndma) {
-                int slot = slot0 + lane;
-                slot = slot < ndma ? slot : ndma - 1;        // lanes past the end re-read the last slot
+            const int slot0 = (j * (kThreads / 64) + wave_u) * 64;
+            if (slot0 + 64 <= ndma) {
+                __builtin_amdgcn_global_load_lds((gptr_t *)(lane_src + slot0), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
+            } else if (slot0 < ndma) {                        // the window's last group: lanes past the end re-read the last slot
+                const int slot = slot0 + lane < ndma ? slot0 + lane : ndma - 1;
                 __builtin_amdgcn_global_load_lds((gptr_t *)(src4 + q0 + slot), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
             }
         }

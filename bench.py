@@ -45,6 +45,7 @@ import argparse
 import ctypes
 import gc
 import json
+import re
 import math
 import os
 import sys
@@ -178,6 +179,31 @@ def detect_kernel(hd_cap, detect_kernel_knob):
         return 'k_detect_rows', ('k_detect_rows (objectness column, then the surviving rows: decode + score filter + '
                                  'candidate compaction)')
     return 'k_stream_wave', 'k_stream_wave (wave-private tiles, reads the whole head: decode + score filter + candidate compaction)'
+
+
+def load_valu_busy(workload, kernel):
+    """Vector-ALU occupancy of a kernel from the committed SQ counter pass (tools/pmc_sq.sh): the share of
+    the SIMDs' cycles spent issuing VALU instructions.  SQ_ACTIVE_INST_VALU counts four-cycle issue slots
+    summed over all SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines of the 8 XCDs."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_%s_sq.txt' % workload)
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    vals = {}
+    for line in lines:
+        if kernel in line.split(' ', 1)[0]:
+            for m in re.finditer(r'(\w+)=([-+.\deE]+)\(n=\d+\)', line):
+                vals[m.group(1)] = float(m.group(2))
+    if 'SQ_ACTIVE_INST_VALU' not in vals or 'SQ_BUSY_CYCLES' not in vals:
+        return None
+    simds, engines = 1024, 32
+    busy = 4.0 * vals['SQ_ACTIVE_INST_VALU'] / (simds * vals['SQ_BUSY_CYCLES'] / engines)
+    return dict(valu_instructions_per_launch=int(vals.get('SQ_INSTS_VALU', 0)), valu_busy_frac=round(busy, 3),
+                source='profiles/r02_%s_sq.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_sq.sh)' % workload,
+                note='share of SIMD cycles issuing vector-ALU instructions while the kernel runs' +
+                     ('; the loss kernel is bound by vector-ALU issue and its prologue latency, not by HBM'
+                      if kernel == 'k_loss_main' else ''))
 
 
 def load_traffic(workload, kernel):
@@ -459,8 +485,10 @@ def main():
             torch.cuda.synchronize(dev)
             runs.append(a.elapsed_time(b) / 100)
         kern_runs = runs
-        timing = ('HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run): the loss '
-                  'kernel plus its one-workgroup finalize launch, no all-reduce')
+        timing = ('HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run), no all-reduce: ' +
+                  ('two launches per call, k_loss_main (loss sums and the gradient tensor in one pass) and '
+                   'k_loss_grad_pos_finalize (the assigned rows\' terms); traffic adds up both'
+                   if w.get('backward') else 'one launch per call, k_loss_main, whose last workgroup combines the partial sums'))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')
     if world > 1:
@@ -488,6 +516,10 @@ def main():
                                 'barriers' % steps),
         }
         rec = load_traffic(args.workload, kname)
+        if rec and w.get('backward'):                       # the call's second launch
+            rec2 = load_traffic(args.workload, 'k_loss_grad_pos')
+            if rec2:
+                rec = dict(rec, bytes_per_launch=rec['bytes_per_launch'] + rec2['bytes_per_launch'])
         algo = float(B * bytes_img)
         model = rows_traffic_model(rows_per_launch, config.get('row_survival', 1.0), K) if kname == 'k_detect_rows' else (
             rows_per_launch * 128.0 if kname == 'k_loss_main' else algo)
@@ -514,6 +546,9 @@ def main():
                    % (config.get('row_survival', 0.0), nstreams) if kname == 'k_detect_rows' else '')))
         if surv0 is not None:
             res['roofline']['row_survival'] = config['row_survival']
+        valu = load_valu_busy(args.workload, kname)
+        if valu:
+            res['roofline']['valu'] = valu
         res['roofline']['achievable_read_gbs'] = round(measured_read_bandwidth(sets, dev), 1)
         res['roofline']['frac_of_achievable'] = round(ach / res['roofline']['achievable_read_gbs'], 4)
         if args.workload == 'detect416' and kname == 'k_detect_rows' and not args.no_sweep and world == 1:

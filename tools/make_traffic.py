@@ -5,7 +5,7 @@ HBM bytes per launch of a kernel = FETCH_SIZE [KiB] x 1024 x 2 (on gfx950 FETCH_
 requests at 64 bytes) + WRITE_SIZE [KiB] x 1024; TCC_MISS_sum x 128 bytes is kept as the cross-check."""
 import json, os, re, sys
 KERNELS = {'k_detect_rows': 'yh::k_detect_rows', 'k_stream_wave': 'yh::k_stream_wave', 'k_stream': 'yh::k_stream<',
-           'k_loss_main': 'yh::k_loss_main', 'k_sort_nms': 'yh::k_sort_nms', 'k_post': 'yh::k_post'}
+           'k_loss_main': 'yh::k_loss_main', 'k_loss_grad_pos': 'yh::k_loss_grad_pos', 'k_sort_nms': 'yh::k_sort_nms', 'k_post': 'yh::k_post'}
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')
 try:
     out = json.load(open(out_path))

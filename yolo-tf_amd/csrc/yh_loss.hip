@@ -25,7 +25,6 @@ __device__ unsigned long long g_loss_trace[kLossTraceGroups * kLossTraceWords];
 constexpr int kPosThreads = kLossNegThreads;     // the positive branch shares the negative branch's launch
 constexpr int kPairStride = 12;              // floats per pair of ground-truth rows in LDS (16-byte aligned)
 constexpr float kLossFastBound = 0x1p40f;
-constexpr int kLossObjTurn = 4;               // the turn of the IoU loop that asks for the objectness logits (even)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // fminf / fmaxf as the bare instructions (IEEE mode: a NaN operand yields the other one, as
@@ -259,7 +258,7 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
 
     // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart.  The
     // objectness logits are not needed before the IoU loop below has run, and the loop hides
-    // their latency.  They are asked for a few turns into the loop rather than here: the
+    // their latency.  They are asked for halfway through the loop rather than here: the
     // workgroups of a compute unit start within a microsecond or two of each other, and a table
     // store of a late one queued behind the objectness loads of an early one in the unit's
     // memory pipeline (some 40 MB for the whole launch) waited up to 10 us for its acknowledgement.
@@ -457,10 +456,11 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             // loaded is not touched.
             Turn ta, tb;
             const int last = turns - 1;
+            const int obj_turn = (turns >> 1) & ~1;           // halfway through the loop (measured at 25 turns: 2, 4: 29.5 us per call, 8: 28.7, 12: 27.2, 16: 28.0, after the loop: 28.5)
             if (turns > 0) { turn_issue(ta, tab); turn_wait(ta); }
             for (int t = 0; t < turns; t += 2) {
                 turn_issue(tb, tab + (t + 1 < last ? t + 1 : last) * (2 * kPairStride));
-                if (t == kLossObjTurn) ask_obj();
+                if (t == obj_turn) ask_obj();
                 if (GRAD) fill_some();
                 turn_steps(ta);
                 turn_wait(tb);

@@ -35,8 +35,8 @@
 namespace yh {
 
 constexpr int kThreads = 256;
-constexpr int kStage = 384;      // candidate keys staged per workgroup
-constexpr int kHitCap = 896;     // class logits that passed the prefilter, collected before they are worked on
+constexpr int kStage = 768;      // candidate keys staged per workgroup
+constexpr int kHitCap = 512;     // class logits that passed the prefilter, collected before they are worked on
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -145,9 +145,14 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     const float4 *src4 = reinterpret_cast<const float4 *>(sc.src);
     const float pf = (MODE == kModeConf) ? p.thr : p.prefilter;
 
-    const uint32_t row_begin = chunk * sc.tiles_per_chunk * (uint32_t)R;
-    uint32_t row_end = row_begin + sc.tiles_per_chunk * (uint32_t)R;
-    if (row_end > sc.rows_img) row_end = sc.rows_img;
+    // The workgroup's tiles are chunk, chunk + chunks_per_img, chunk + 2 * chunks_per_img, ... of the image:
+    // the workgroups that are resident together (consecutive launch ids) then read one contiguous,
+    // advancing window of memory, whatever the number of tiles each takes.  (With a run of consecutive
+    // tiles per workgroup the kernel's time swung by 8 % with the run's length: 955 us at 48 tiles,
+    // 900 at 6, 976 at 7, 949 at 8, 906 at 9 on config 5 at batch 128.)
+    const uint32_t tile_stride = sc.chunks_per_img * (uint32_t)R;
+    const uint32_t row_begin = chunk * (uint32_t)R;
+    const uint32_t row_end = sc.rows_img;
 
     // HBM -> LDS, the whole tile in flight at once
     auto issue = [&](uint32_t row_t) {
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         }
     };
     if (row_begin < row_end) issue(row_begin);
-    for (uint32_t row_t = row_begin; row_t < row_end; row_t += (uint32_t)R) {
+    for (uint32_t row_t = row_begin; row_t < row_end; row_t += tile_stride) {
         const int rows_t = (int)((row_end - row_t) < (uint32_t)R ? (row_end - row_t) : (uint32_t)R);
         const long long f0 = s0 + (long long)row_t * K;
         const int sh = (int)(f0 & 3);
@@ -253,8 +258,10 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         // global atomic, and that wait and the loads' flight time then overlap.
         const int staged = st.count;
         if (tid == 0) st.nhits = 0;
-        if (row_t + (uint32_t)R < row_end) issue(row_t + (uint32_t)R);
-        if (staged >= kStage / 2) flush_candidates(st, p, b, staged);
+        if (row_t + tile_stride < row_end) issue(row_t + tile_stride);
+        // late: a flush costs a round trip to the image's counter with the whole workgroup waiting; what does
+        // not fit the stage any more goes to the list key by key (push_candidate), slower but as correct
+        if (staged >= kStage - 128) flush_candidates(st, p, b, staged);
     }
     __syncthreads();
     flush_candidates(st, p, b, st.count);

@@ -800,7 +800,7 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
     if (p.pos_blocks < 1) p.pos_blocks = 1;
 }
 
-struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *pair_tab; size_t bytes; };
+struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *pair_tab; yh::PosRecord *pos_rec; size_t bytes; };
 
 static LossWs carve_loss(void *base, const yh::LossParams &p)
 {
@@ -813,11 +813,13 @@ static LossWs carve_loss(void *base, const yh::LossParams &p)
     const size_t o_pos = take((size_t)p.B * p.pos_blocks * 3 * 4);
     const size_t o_g = take((size_t)p.B * 4);
     const size_t o_pp = take((size_t)p.B * p.S * p.pair_cap * 12 * 4);
+    const size_t o_pr = take((size_t)p.B * p.pos_blocks * yh::kLossPosGtPerBlock * sizeof(yh::PosRecord));
     w.pair = reinterpret_cast<double *>(c + o_pair);
     w.neg = reinterpret_cast<float *>(c + o_neg);
     w.pos = reinterpret_cast<float *>(c + o_pos);
     w.gcount = reinterpret_cast<int32_t *>(c + o_g);
     w.pair_tab = reinterpret_cast<float *>(c + o_pp);
+    w.pos_rec = reinterpret_cast<yh::PosRecord *>(c + o_pr);
     w.bytes = off;
     return w;
 }
@@ -894,6 +896,7 @@ static int loss_forward(const yh_head_config *cfg, const float *const *heads, co
     p.gt = ground_truth;
     p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount; p.reduce_pair = w.pair;
     p.pair_tab = w.pair_tab;
+    p.pos_rec = grad_per_image ? w.pos_rec : nullptr;
     p.cu_slots = compute_units();
     // The last workgroup of the main launch finalizes while the launch is small enough for the tickets
     // (one atomic per workgroup on one address) to cost less than a launch of their own; measured at

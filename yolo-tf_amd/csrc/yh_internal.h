@@ -200,6 +200,14 @@ struct LossScale {
     float prior_hw[YH_MAX_PRIORS][2];
 };
 
+// What the forward pass's positive branch leaves for the gradient launch that follows it: the
+// assignment and targets of one ground-truth row.
+struct PosRecord {
+    long long at;        // first float of the assigned row inside its head tensor; -1: no term
+    int32_t s, label;    // scale, class
+    float fy, fx, lh, lw;
+};
+
 struct LossParams {
     int32_t S, B, C, P, K, N, pad;
     int32_t blocks_per_img;       // negative-branch blocks per image (all scales)
@@ -218,6 +226,7 @@ struct LossParams {
     double *reduce_pair;          // [2] at the start of the workspace: fp64 sum of the per-image losses, image count
     uint8_t *noobj_mask;          // [B][N] or null: 1 where the box enters the no-object sum
     const float *grad_w;          // backward: [B] upstream gradient of every per-image loss
+    PosRecord *pos_rec;           // [B][pos_blocks][kLossPosGtPerBlock], written when grad_w is set; null in the backward-only launches
     float *pair_tab;              // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side:
                                   //   written and read back by the negative-branch workgroups of the main launch
     int32_t pair_cap;             // pairs per (image, scale) in pair_tab: even, >= ceil(pad / 2)

@@ -642,6 +642,8 @@ __device__ __forceinline__ int pos_assign(const LossParams &p, int b, int blk, i
         float *growp = nullptr;
         float fy = 0.0f, fx = 0.0f, lh = 0.0f, lw = 0.0f;
         int label = -1;
+        long long rec_at = -1;
+        int rec_s = 0;
         if (tid < n) {
             const GtAssign a = assign_gt(p, p.gt + ((long long)b * p.pad + g0 + tid) * 5);
             if (a.inside) {
@@ -655,6 +657,7 @@ __device__ __forceinline__ int pos_assign(const LossParams &p, int b, int blk, i
                 const long long at = ((long long)b * rows_img + a.row) * p.K;
                 rowp = base + at;
                 growp = want_grad ? gbase + at : nullptr;
+                rec_at = at; rec_s = a.s;
                 fy = a.gy - floorf(a.gy); fx = a.gx - floorf(a.gx);
                 lh = logf(a.gh / a.prior_h); lw = logf(a.gw / a.prior_w);
                 label = a.label;
@@ -662,9 +665,35 @@ __device__ __forceinline__ int pos_assign(const LossParams &p, int b, int blk, i
         }
         l.rowp[tid] = rowp; l.growp[tid] = growp;
         l.fy[tid] = fy; l.fx[tid] = fx; l.lh[tid] = lh; l.lw[tid] = lw; l.label[tid] = label;
+        if (p.pos_rec) {                                        // the gradient launch that follows starts from here
+            PosRecord rec;
+            rec.at = rec_at; rec.s = rec_s; rec.label = label;
+            rec.fy = fy; rec.fx = fx; rec.lh = lh; rec.lw = lw;
+            p.pos_rec[((long long)b * p.pos_blocks + blk) * kLossPosGtPerBlock + tid] = rec;
+        }
     }
     __syncthreads();
     return n;
+}
+
+// Phase one of the gradient launch behind a forward pass in the same call: the records that pass left.
+__device__ __forceinline__ int pos_from_records(const LossParams &p, int b, int blk, PosLds &l)
+{
+    const int tid = threadIdx.x;
+    if (tid < kLossPosGtPerBlock) {
+        const PosRecord rec = p.pos_rec[((long long)b * p.pos_blocks + blk) * kLossPosGtPerBlock + tid];
+        const float *rowp = nullptr;
+        float *growp = nullptr;
+        if (rec.at >= 0) {
+#pragma unroll
+            for (int s = 0; s < YH_MAX_SCALES; ++s)
+                if (s < p.S && s == rec.s) { rowp = p.sc[s].head + rec.at; growp = p.sc[s].grad + rec.at; }
+        }
+        l.rowp[tid] = rowp; l.growp[tid] = growp;
+        l.fy[tid] = rec.fy; l.fx[tid] = rec.fx; l.lh[tid] = rec.lh; l.lw[tid] = rec.lw; l.label[tid] = rec.label;
+    }
+    __syncthreads();
+    return kLossPosGtPerBlock;
 }
 
 // ---------------------------------------------------------------- positive
@@ -934,8 +963,14 @@ __device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t bloc
     const int b = (int)(block / (uint32_t)p.pos_blocks);
     const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
-    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
-    const int n = pos_assign(p, b, blk, G, l, true);
+    int G, n;
+    if (p.pos_rec) {                                           // behind a forward pass of the same call
+        G = p.gcount[b];
+        n = pos_from_records(p, b, blk, l);
+    } else {
+        G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+        n = pos_assign(p, b, blk, G, l, true);
+    }
     const int C = p.C, K = p.K;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;
     float w = p.grad_w[b];

@@ -13,8 +13,11 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *    all work is enqueued on it and no entry point synchronises with the host;
  *  - calls on different (device, stream, workspace) triples may run
- *    concurrently; the only process-wide state is the launch-plan tuning of
- *    yh_set_tuning (never the process environment);
+ *    concurrently; the only process-wide setting is the launch-plan tuning of
+ *    yh_set_tuning (never the process environment).  The library keeps two
+ *    device arrays of its own per GPU: the scratch of yh_detect_static and a
+ *    small ring of counters used by yh_loss (zero between calls, one cell per
+ *    call in flight);
  *  - heads are the NHWC head tensors [B][H][W][P*(C+5)] fp32, one per scale,
  *    channel order per prior = C class logits, t_y, t_x, t_h, t_w, objectness
  *    (YOLOv3.py:95-102, YOLOv2.py:96-100); `heads` itself is a HOST array of

@@ -9,6 +9,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
 import yolo_tf_amd as y
+from yolo_tf_amd import _abi
 
 dev = torch.device('cuda:0')
 s = [8., 16., 32.]
@@ -19,12 +20,11 @@ sets = [y.synth.torch_heads(dev, i, 64, grids, 3, 80) for i in range(4)]
 outs = hd._alloc_outputs(64, 10, dev, False)
 ref = None
 for spec in sys.argv[1:]:
-    ni, nbuf, units, dbg = (spec.split(':') + ['0'])[:4]
-    os.environ['YH_DEBUG'] = dbg
+    ni, nbuf, units = spec.split(':')[:3]
     hd._ws.clear(); hd._plans.clear()
-    os.environ['YH_STREAM_NI'] = ni
-    os.environ['YH_STREAM_NBUF'] = nbuf
-    os.environ['YH_STREAM_UNITS' if ni in ('4', '8') else 'YH_STREAM_BLOCKS'] = units
+    wave = ni in ('4', '8')
+    _abi.set_tuning(detect_kernel=2, stream_tile_kib=int(ni), stream_buffers=int(nbuf),
+                    stream_units=int(units) if wave else 0, stream_blocks=0 if wave else int(units))
     for i in range(20):
         hd.detect(sets[i % 4], 0.5, 0.5, 10, max_candidates=2048, outputs=outs)
     torch.cuda.synchronize()

@@ -4,6 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, yolo_tf_amd as y
+from yolo_tf_amd import _abi
 dev = torch.device('cuda:0')
 w = bench.WORKLOADS['detect416']
 grids, priors, box_mult, gt_rate = bench.build_head(w)
@@ -11,7 +12,7 @@ for obj_mean in (-4.0, -2.0, -1.0, 0.0, 2.0):
     sets = [y.synth.torch_heads(dev, i, 64, grids, 3, 80, obj_mean=obj_mean, hot_mean=-3.0) for i in range(4)]
     row = []
     for kind in ('1', '2'):
-        os.environ['YH_DETECT_KERNEL'] = kind
+        _abi.set_tuning(detect_kernel=int(kind))
         hd = y.DetectionHead(80, priors, box_mult, gt_rate)
         pipe = y.DetectPipeline(hd, 0.5, 0.5, 10)
         for i in range(10):

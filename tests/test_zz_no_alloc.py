@@ -96,3 +96,18 @@ def test_static_scratch_rejects_what_does_not_fit(gpu):
     assert rc == _abi.YH_ERR_LIMIT and b'static scratch' in lib.yh_last_error()
     # an empty batch is fine and touches nothing
     assert lib.yh_detect_static(ctypes.byref(cfg), None, 0, 0.5, 0.5, mb, cap, *[None] * 7, None) == _abi.YH_OK
+
+
+def test_python_wrapper_of_the_static_entry_point(gpu):
+    """DetectionHead.detect_static against DetectionHead.detect on the same batch."""
+    case = cases.v3(416)
+    heads = [torch.from_numpy(h).to(gpu) for h in y.synth.make_heads(31, 3, case.grids, case.P, case.C)]
+    hd = y.DetectionHead(case.C, case.priors, case.box_mult, case.gt_rate)
+    want = hd.detect(heads, 0.5, 0.5, 10, max_candidates=512, want_class_candidates=True)
+    outs = hd._alloc_outputs(3, 10, gpu, True)
+    got = hd.detect_static(heads, 0.5, 0.5, 10, 512, outs)
+    assert not got.overflowed()
+    for (gs, gb, gc, gi), (ws, wb, wc, wi) in zip(got.per_image(), want.per_image()):
+        assert np.array_equal(gi, wi) and np.array_equal(gc, wc)
+        assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        assert np.array_equal(gb.view(np.uint32), wb.view(np.uint32))

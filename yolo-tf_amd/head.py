@@ -270,6 +270,24 @@ class DetectionHead:
                                    want_class_candidates, _auto=auto, stream=stream)
         return Detections(*outputs, rerun, stream=stream)
 
+    def detect_static(self, heads, score_threshold, iou_threshold, max_boxes, max_candidates, outputs,
+                      stream=None):
+        """detect() through yh_detect_static: no workspace of the caller's and no allocation by the
+        call (`outputs` from _alloc_outputs are the caller's, made beforehand) — for code under HIP
+        graph capture or serving loops that must not allocate.  The library's scratch array is shared
+        by every such call on the GPU: calls must not overlap in time.  Capacity is fixed by the
+        caller; an overflow is reported in the status words and not rerun here."""
+        lib = _abi.load()
+        heads = self._check_heads(heads)
+        dev = heads[0].device
+        cfg = self.config_for(heads)
+        args = [ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), heads[0].shape[0],
+                float(score_threshold), float(iou_threshold), int(max_boxes), int(max_candidates)] + \
+            self._output_pointers(outputs) + [self._stream(dev) if stream is None else ctypes.c_void_p(stream.cuda_stream)]
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_detect_static(*args))
+        return Detections(*outputs, None, stream=stream)
+
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
             want_class_candidates=False, _auto=False):
         """Score filter + per-class NMS on decoded inputs (YOLOv3.py:351-368).

@@ -20,10 +20,14 @@ ptrs = [_abi.pointer_array([h.data_ptr() for h in hs]) for hs in sets]
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 scales = (ctypes.c_float * 4)(1., 1., 5., 1.)
 per, total = torch.empty(B, device=dev), torch.empty(2, device=dev)
+GRAD = bool(int(os.environ.get('AB_GRAD', 0)))                   # time yh_loss_with_grad instead of yh_loss
+gw = torch.full((B,), 0.5 / B, device=dev)
+grads = [torch.empty_like(h) for h in sets[0]]
+gptr = _abi.pointer_array([g.data_ptr() for g in grads])
 libs = []
 for path in sys.argv[1:3]:
     lib = ctypes.CDLL(os.path.abspath(path))
-    for name in ('yh_loss_workspace_bytes', 'yh_loss'):
+    for name in ('yh_loss_workspace_bytes', 'yh_loss', 'yh_loss_with_grad'):
         fn = getattr(lib, name); fn.restype, fn.argtypes = _abi.SIGNATURES[name]
     nbytes = ctypes.c_size_t(0)
     assert lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, w['pad'], ctypes.byref(nbytes)) == 0
@@ -32,8 +36,13 @@ res, vals = {}, {}
 for rep in range(5):
     for name, lib, ws in libs:
         def go(i):
-            rc = lib.yh_loss(ctypes.byref(cfg), ptrs[i % 12], gts[i % 12].data_ptr(), B, w['pad'], scales, 0.5, 1,
-                             ws.data_ptr(), ws.numel(), per.data_ptr(), None, None, total.data_ptr(), st)
+            if GRAD:
+                rc = lib.yh_loss_with_grad(ctypes.byref(cfg), ptrs[i % 12], gts[i % 12].data_ptr(), B, w['pad'], scales, 0.5, 1,
+                                           ws.data_ptr(), ws.numel(), per.data_ptr(), None, None, total.data_ptr(),
+                                           gw.data_ptr(), gptr, st)
+            else:
+                rc = lib.yh_loss(ctypes.byref(cfg), ptrs[i % 12], gts[i % 12].data_ptr(), B, w['pad'], scales, 0.5, 1,
+                                 ws.data_ptr(), ws.numel(), per.data_ptr(), None, None, total.data_ptr(), st)
             assert rc == 0, rc
         for i in range(12):
             go(i)

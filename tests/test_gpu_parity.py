@@ -670,6 +670,37 @@ def test_fused_loss_and_gradient_equal_the_two_calls(gpu, version, size, B, G, p
     assert sum(int((g != 0).sum()) for g in one['grads']) > 0
 
 
+def test_loss_finalize_tickets_survive_their_ring_wrapping_around(gpu):
+    """The forward call's last workgroup finds out that it is the last through a ticket cell of a
+    library-owned ring (4096 cells, one per call in flight, put back to zero by the workgroup that
+    finalizes).  More calls than the ring has cells, alternating two shapes and two streams: every
+    call's sum must be what the first call of its shape gave, and a poisoned output must be
+    overwritten every time (a call whose last workgroup did not notice leaves it untouched)."""
+    case = cases.v3(size=96)
+    hd = [case.head_obj(), case.head_obj()]                  # a workspace each: the calls overlap on two streams
+    streams = [torch.cuda.Stream(gpu), torch.cuda.Stream(gpu)]
+    data, ref, outs = [], [], []
+    for k, (B, G, pad) in enumerate(((2, 3, 5), (5, 1, 9))):
+        heads = y.synth.torch_heads(gpu, 880 + k, B, case.grids, case.P, case.C, obj_mean=-1.0)
+        gt = torch.from_numpy(y.synth.make_ground_truth(890 + k, B, G, pad, 96, case.C)).to(gpu)
+        data.append((heads, gt))
+        out = hd[k].loss(heads, gt, 1., 1., 5., 1., 0.5, True)
+        ref.append(out['sum'].clone())
+        outs.append(out)
+    torch.cuda.synchronize(gpu)
+    for i in range(4400):
+        k = i & 1
+        with torch.cuda.stream(streams[k]):
+            outs[k]['sum'].fill_(float('nan'))
+            outs[k] = hd[k].loss(*data[k], 1., 1., 5., 1., 0.5, True, out=outs[k])
+        if i % 400 >= 398 or i >= 4390:
+            streams[k].synchronize()
+            assert torch.equal(outs[k]['sum'], ref[k]), i
+    torch.cuda.synchronize(gpu)
+    for k in (0, 1):
+        assert torch.equal(outs[k]['sum'], ref[k])
+
+
 def test_loss_outputs_can_be_reused(gpu):
     """loss(out=previous result) writes the same tensors again and gives the fresh call's values."""
     case = cases.v3(size=96)

@@ -701,6 +701,30 @@ def test_loss_finalize_tickets_survive_their_ring_wrapping_around(gpu):
         assert torch.equal(outs[k]['sum'], ref[k])
 
 
+def test_loss_workspace_reused_with_new_ground_truth(gpu, c_oracle):
+    """The ground-truth table lives in the workspace and is read back through the scalar data
+    cache: calls in a row on ONE workspace with different ground truth (a training loop) must each
+    see their own table, not a cached line of the call before.  Ignore mask bit for bit and the
+    per-image losses against a fresh head object (fresh workspace) and the C oracle."""
+    case = cases.v3(size=160)
+    B, pad = 6, 24
+    heads = y.synth.torch_heads(gpu, 930, B, case.grids, case.P, case.C, obj_mean=-1.0)
+    hd = case.head_obj()
+    gts = [y.synth.make_ground_truth(940 + rep, B, (3, 23, 1, 17, 8, 23, 2, 11)[rep], pad, 160, case.C) for rep in range(8)]
+    dev_gts = [torch.from_numpy(g).to(gpu) for g in gts]
+    torch.cuda.synchronize(gpu)
+    # back to back, nothing between the launches but the stream's order
+    gots = [hd.loss(heads, g, 1., 1., 5., 1., 0.5, True, want_mask=True) for g in dev_gts]
+    for rep, (g, got) in enumerate(zip(dev_gts, gots)):
+        fresh = case.head_obj().loss(heads, g, 1., 1., 5., 1., 0.5, True, want_mask=True)
+        assert torch.equal(got['noobj_mask'], fresh['noobj_mask']), rep
+        assert torch.equal(got['per_image'], fresh['per_image']), rep
+        if rep in (0, 5):
+            per, _, _, _ = c_oracle.loss(case.oracle_cfg(c_oracle), [h.cpu().numpy() for h in heads], gts[rep],
+                                         (1., 1., 5., 1.), 0.5, True)
+            assert_close(got['per_image'].cpu().numpy(), per, what='per-image loss')
+
+
 def test_loss_outputs_can_be_reused(gpu):
     """loss(out=previous result) writes the same tensors again and gives the fresh call's values."""
     case = cases.v3(size=96)

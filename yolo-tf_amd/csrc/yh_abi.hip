@@ -794,7 +794,10 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
         blk += (sc.rows_img + yh::kLossNegRows - 1) / yh::kLossNegRows;
         row_base += sc.rows_img;
     }
-    p.pair_cap = 2 * ((pad + 3) / 4);
+    // pairs per table: whole turns of the loop (two pairs), and a multiple of eight so that a table is a whole
+    // number of 128-byte lines: the scalar data cache is not coherent with the vector stores that write the
+    // tables, and a line shared by two tables could be cached before its second half is written
+    p.pair_cap = 8 * ((2 * ((pad + 3) / 4) + 7) / 8);
     p.blocks_per_img = (int32_t)blk;
     p.pos_blocks = (pad + yh::kLossPosGtPerBlock - 1) / yh::kLossPosGtPerBlock;
     if (p.pos_blocks < 1) p.pos_blocks = 1;

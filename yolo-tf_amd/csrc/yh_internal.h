@@ -229,7 +229,7 @@ struct LossParams {
     PosRecord *pos_rec;           // [B][pos_blocks][kLossPosGtPerBlock], written when grad_w is set; null in the backward-only launches
     float *pair_tab;              // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side:
                                   //   written and read back by the negative-branch workgroups of the main launch
-    int32_t pair_cap;             // pairs per (image, scale) in pair_tab: even, >= ceil(pad / 2)
+    int32_t pair_cap;             // pairs per (image, scale) in pair_tab: a multiple of 8 (whole 128-byte lines), >= ceil(pad / 2)
     int32_t ticket_slot;          // the launch's cell of the library's ticket array; -1: a launch of its own finalizes
     int32_t cu_slots;             // compute units of the device (0: keep the launch order of the negative-branch blocks)
     LossScale sc[YH_MAX_SCALES];

@@ -169,7 +169,7 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
 // Short runs of tiles per workgroup keep the workgroups that are resident together on neighbouring
-// addresses (config 5 at batch 128, 177792 tiles: 3600 workgroups 955 us, 10240: 931, 20480: 902, 30000: 896,
+// addresses (128 images of 100x100x10 boxes, 80 classes, 177792 tiles: 3600 workgroups 955 us, 10240: 931, 20480: 902, 30000: 896,
 // 45000: 1045).
 constexpr uint64_t kStreamTilesPerBlock = 8;
 

@@ -168,9 +168,10 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 // (the atomic that reserves its candidate range), so the launch is
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
-// Short runs of tiles per workgroup keep the workgroups that are resident together on neighbouring
-// addresses (128 images of 100x100x10 boxes, 80 classes, 177792 tiles: 3600 workgroups 955 us, 10240: 931, 20480: 902, 30000: 896,
-// 45000: 1045).
+// Few tiles per workgroup: what a workgroup stages then leaves in one flush at its end (a flush is a
+// round trip to the image's candidate counter with the whole workgroup waiting), and the launch ends
+// without a long tail.  128 images of 100x100x10 boxes, 80 classes, one candidate per box: 48 tiles per
+// workgroup 945 us, 15: 904, 9: 883, 8: 877.
 constexpr uint64_t kStreamTilesPerBlock = 8;
 
 constexpr uint64_t kStreamTargetUnits = 8192;

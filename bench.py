@@ -16,6 +16,8 @@ Workloads (BASELINE.json configs):
   detect_v2  config 1  YOLOv2-416 VOC-20, batch 1 (latency-bound: one image)
   detect608  config 4  YOLOv3-608 COCO-80, batch 64 / GPU
   stress     config 5  100x100 grid x 10 priors, ~1e5 candidates / image at thr 0.001, batch 128 / GPU
+  nms_seam   config 5 entered at the post-decode seam: boxes [B,N,4] and conf [B,N,C] resident in HBM,
+             score filter + per-class NMS only (yh_nms)
 
 Rank 0 prints ONE JSON line.
 
@@ -73,6 +75,9 @@ WORKLOADS = {
                       name='YOLOv3 608x608 COCO-80 decode+NMS, synthetic head tensors, 22743 boxes/img'),
     'stress': dict(kind='detect', size=None, C=80, batch=128, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
                    name='NMS stress: 100x100 grid x 10 priors, ~1e5 candidates/img at score_thresh 0.001, 80 classes'),
+    'nms_seam': dict(kind='nms', size=None, C=80, batch=128, thr=0.001, iou=0.5, max_boxes=100, dist=y.synth.STRESS,
+                     name='NMS stress at the post-decode seam: decoded boxes [B,N,4] + conf [B,N,C] resident, score filter '
+                          '+ per-class NMS (100x100 grid x 10 priors, ~1e5 candidates/img at score_thresh 0.001, 80 classes)'),
     'loss416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101,
                     name='YOLOv3 416x416 training loss path: 100 GT boxes/img IoU ignore-mask + target assignment'),
     'train416': dict(kind='loss', size=416, C=80, batch=32, G=100, pad=101, backward=True,
@@ -115,7 +120,10 @@ def cpu_baseline(w, grids, priors, box_mult, gt_rate):
 
     def sample(n_img, nthreads, budget):
         heads = y.synth.make_heads(4242, n_img, grids, P, w['C'], **w.get('dist', {}))
-        if w['kind'] == 'detect':
+        if w['kind'] == 'nms':                               # decoded once, outside the timed passes
+            dboxes, dconf = co.decode(cfg, heads, True, threads)
+            fn = lambda: co.nms(dboxes, dconf, w['thr'], w['iou'], w['max_boxes'], threads=nthreads)
+        elif w['kind'] == 'detect':
             fn = lambda: co.detect(cfg, heads, w['thr'], w['iou'], w['max_boxes'], threads=nthreads, unpack=False)
         else:
             gt = y.synth.make_ground_truth(4243, n_img, w['G'], w['pad'], w['size'], w['C'])
@@ -131,7 +139,10 @@ def cpu_baseline(w, grids, priors, box_mult, gt_rate):
     res['single_thread'] = dict(value=round(rate1, 2), unit='images/sec', cores=1, kind='port', sample=what1 + ', the same C code on one thread')
     # NumPy restatement (oracle/yolo_head_oracle.py), one image per pass
     h0 = [h[0] for h in heads1]
-    if w['kind'] == 'detect':
+    if w['kind'] == 'nms':
+        nb, nc = O.decode(h0, priors, box_mult, w['C'])
+        fn = lambda: O.nms_per_class(nb, nc, w['thr'], w['max_boxes'], w['iou'])
+    elif w['kind'] == 'detect':
         fn = lambda: O.detect(h0, priors, box_mult, w['C'], w['thr'], w['max_boxes'], w['iou'])
     elif w.get('version') == 2:
         gt = y.synth.make_ground_truth(4243, 1, w['G'], w['pad'], w['size'], w['C'])
@@ -350,7 +361,24 @@ def main():
 
     # ---- inputs: enough distinct sets that a step never re-reads lines the Infinity Cache still holds,
     # sized by the bytes a step TOUCHES (the objectness-first kernel and the loss touch a fraction of a set)
-    if w['kind'] == 'detect':
+    decoded = None
+    if w['kind'] == 'nms':
+        # the post-decode seam: every input set is a decoded batch (boxes [B,N,4], conf [B,N,C]); the head
+        # tensors it came from are dropped again
+        def decoded_set(seed):
+            hs = y.synth.torch_heads(dev, seed, B, grids, P, C, **w.get('dist', {}))
+            out = hd.decode(hs)
+            del hs
+            return out
+        probe, surv0 = None, None
+        kname, kdesc = 'k_stream', 'k_stream<conf> (workgroup tiles over the confidence matrix: score filter + candidate compaction)'
+        touched = float(rows_per_launch) * (C * 4 + 16)
+        rotate = rotation_for(touched, cap=4)
+        decoded = [decoded_set(1000 * rank + i) for i in range(rotate)]
+        torch.cuda.empty_cache()
+        hd.nms(decoded[0][0], decoded[0][1], w['thr'], w['iou'], w['max_boxes']).resolved()   # settles the capacity (untimed)
+        sets = [[c] for _, c in decoded]                     # what the read-bandwidth yardstick streams
+    elif w['kind'] == 'detect':
         probe = y.synth.torch_heads(dev, 1000 * rank, B, grids, P, C, **w.get('dist', {}))
         surv0 = row_survival([probe], C, w['thr'])
         hd.detect(probe, w['thr'], w['iou'], w['max_boxes']).resolved()     # settles the candidate capacity (untimed)
@@ -360,9 +388,12 @@ def main():
         probe, surv0 = None, None
         kname, kdesc = 'k_loss_main', 'k_loss_main (ignore-mask IoU loop + assignment + loss sums; reads the objectness column and the assigned rows)'
         touched = rows_per_launch * 128.0 * (3.0 if w.get('backward') else 1.0)
-    rotate = rotation_for(touched, cap=24 if B * bytes_img < (1 << 30) else 4)
-    sets = [probe if (i == 0 and probe is not None) else
-            y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(rotate)]
+    if decoded is None:
+        rotate = rotation_for(touched, cap=24 if B * bytes_img < (1 << 30) else 4)
+        sets = [probe if (i == 0 and probe is not None) else
+                y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(rotate)]
+    else:
+        bytes_img = N * (C * 4 + 16)                         # what this seam reads per image: conf row + box
     rotation_note = ('%d distinct input sets of %.0f MB, %.0f MB of lines touched per step: %.1fx the 256 MiB Infinity '
                      'Cache between two reads of a line' % (rotate, B * bytes_img / 1e6, touched / 1e6,
                                                             rotate * touched / INFINITY_CACHE_BYTES))
@@ -370,7 +401,13 @@ def main():
     extra = {}
     pipe = None
     nstreams = 1
-    if w['kind'] == 'detect':
+    if w['kind'] == 'nms':
+        outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
+
+        def step(i):
+            bx, cf = decoded[i % rotate]
+            return hd.nms(bx, cf, w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
+    elif w['kind'] == 'detect':
         # Software pipeline over the sequence of batches, as a serving loop would run the path: a
         # step streams batch i and, inside the same launch, selects batch i-1 (yh_detect_pipelined).
         # --in-flight 1 runs every batch to completion before the next (yh_detect).
@@ -436,7 +473,21 @@ def main():
     gc.enable()
 
     kern_runs = None
-    if w['kind'] == 'detect':
+    if w['kind'] == 'nms':
+        if last.overflowed():
+            raise SystemExit('candidate capacity overflow in the benchmark configuration')
+        extra['detections_per_image_last_step'] = round(float(last.count.float().mean().item()), 2)
+        extra['max_candidates'] = hd.default_max_candidates(N)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+        for a, b in evs:                                      # a first record creates the hipEvent_t handles
+            a.record(); b.record()
+        for i, (a, b) in enumerate(evs):
+            bx, cf = decoded[i % rotate]
+            hd.nms(bx, cf, w['thr'], w['iou'], w['max_boxes'], outputs=outputs, stream_events=(a, b))
+        torch.cuda.synchronize(dev)
+        kern_runs = [a.elapsed_time(b) for a, b in evs[2:]]
+        timing = 'HIP event pairs around the kernel in %d yh_nms_timed calls after the timed regions' % len(kern_runs)
+    elif w['kind'] == 'detect':
         if pipe is not None:
             last = pipe.flush()                             # the last batch's select stage (outside the timed regions)
             if isinstance(last, list):
@@ -501,7 +552,7 @@ def main():
         config = dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=B * world,
                       boxes_per_image=N, num_classes=C, bytes_per_image=bytes_img,
                       parallelism='images sharded across %d GPU(s), no data-path collective' % world
-                      if w['kind'] == 'detect' else
+                      if w['kind'] in ('detect', 'nms') else
                       'images sharded across %d GPU(s), one scalar all-reduce (RCCL) per step' % world,
                       input_rotation=rotation_note, **extra)
         if surv0 is not None:

@@ -246,6 +246,18 @@ int yh_nms(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
            int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
            int32_t *status, void *stream);
 
+/* yh_nms with two caller-created hipEvent_t (as void*, either may be NULL)
+ * recorded on `stream` immediately before and after the pass over the
+ * confidence matrix (score filter + candidate compaction), as yh_detect_timed
+ * does for yh_detect.  Measurement hook: no counterpart in the reference. */
+int yh_nms_timed(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
+                 const float *boxes, const float *conf,
+                 float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                 int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                 int32_t *out_count, float *out_scores, float *out_boxes,
+                 int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                 int32_t *status, void *stream, void *event_begin, void *event_end);
+
 /* Training loss of the batch up to the per-image values: replaces
  * YOLOv3.py:117-310 / YOLOv2.py:105-173 (GT normalisation, best-prior and
  * scale assignment, coordinate / class / object sums, the IoU ignore mask and

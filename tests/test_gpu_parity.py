@@ -100,6 +100,29 @@ def test_nms_stage_bit_exact_on_identical_decoded_inputs(gpu, c_oracle, case_fn,
     assert sum(len(g[0]) for g in got) > 0
 
 
+def test_timed_entry_points_give_the_untimed_results(gpu):
+    """yh_detect_timed / yh_nms_timed: the same call with an event recorded on either side of the
+    pass over the input; results equal the plain entry points', the events measure a positive time."""
+    case = cases.v3()
+    heads = to_dev(case.heads(33, 3, obj_mean=-1.0), gpu)
+    hd = case.head_obj()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in evs:
+        e.record()                                             # creates the hipEvent_t handles
+    plain = hd.detect(heads, 0.3, 0.5, 10).per_image()
+    timed = hd.detect(heads, 0.3, 0.5, 10, stream_events=(evs[0], evs[1])).per_image()
+    boxes, conf = hd.decode(heads)
+    plain_n = hd.nms(boxes, conf, 0.3, 0.5, 10).per_image()
+    timed_n = hd.nms(boxes, conf, 0.3, 0.5, 10, stream_events=(evs[2], evs[3])).per_image()
+    torch.cuda.synchronize()
+    for got, want in ((timed, plain), (timed_n, plain_n), (timed_n, plain)):
+        cases.same_detections(got, want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
+    assert evs[0].elapsed_time(evs[1]) > 0 and evs[2].elapsed_time(evs[3]) > 0
+    assert sum(len(g[0]) for g in plain) > 0
+
+
 def _fragile(wbox, wconf_c, thr, iou_thr, tol=1e-5):
     """True when the oracle's own decisions for one (image, class) sit within
     float noise of a boundary: a confidence at the score threshold, two

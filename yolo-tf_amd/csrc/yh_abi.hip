@@ -720,13 +720,13 @@ int yh_detect_pipelined(const yh_head_config *cfg, const float *const *heads, in
     return YH_OK;
 }
 
-int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
-           const float *boxes, const float *conf,
-           float score_threshold, float iou_threshold, int32_t nms_max_boxes,
-           int32_t max_candidates, void *workspace, size_t workspace_bytes,
-           int32_t *out_count, float *out_scores, float *out_boxes,
-           int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
-           int32_t *status, void *stream)
+static int nms_impl(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
+                    const float *boxes, const float *conf,
+                    float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                    int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                    int32_t *out_count, float *out_scores, float *out_boxes,
+                    int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                    int32_t *status, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     int rc = check_nms_args(batch, iou_threshold, nms_max_boxes, max_candidates, workspace, out_count,
                             out_scores, out_boxes, out_class, out_index, status);
@@ -768,7 +768,34 @@ int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
                                             nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
                                             out_class, out_index, out_class_candidates, status);
     const uint32_t blocks = plan_stream(p, batch, yh::kModeConf);
-    return run_pipeline(p, yh::kModeConf, blocks, q, st, nullptr, nullptr);
+    return run_pipeline(p, yh::kModeConf, blocks, q, st, ev_begin, ev_end);
+}
+
+int yh_nms(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
+           const float *boxes, const float *conf,
+           float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+           int32_t max_candidates, void *workspace, size_t workspace_bytes,
+           int32_t *out_count, float *out_scores, float *out_boxes,
+           int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+           int32_t *status, void *stream)
+{
+    return nms_impl(batch, boxes_per_img, num_classes, boxes, conf, score_threshold, iou_threshold, nms_max_boxes,
+                    max_candidates, workspace, workspace_bytes, out_count, out_scores, out_boxes, out_class, out_index,
+                    out_class_candidates, status, stream, nullptr, nullptr);
+}
+
+int yh_nms_timed(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
+                 const float *boxes, const float *conf,
+                 float score_threshold, float iou_threshold, int32_t nms_max_boxes,
+                 int32_t max_candidates, void *workspace, size_t workspace_bytes,
+                 int32_t *out_count, float *out_scores, float *out_boxes,
+                 int32_t *out_class, int32_t *out_index, int32_t *out_class_candidates,
+                 int32_t *status, void *stream, void *event_begin, void *event_end)
+{
+    return nms_impl(batch, boxes_per_img, num_classes, boxes, conf, score_threshold, iou_threshold, nms_max_boxes,
+                    max_candidates, workspace, workspace_bytes, out_count, out_scores, out_boxes, out_class, out_index,
+                    out_class_candidates, status, stream, static_cast<hipEvent_t>(event_begin),
+                    static_cast<hipEvent_t>(event_end));
 }
 
 static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batch, int32_t pad)

@@ -289,9 +289,10 @@ class DetectionHead:
         return Detections(*outputs, None, stream=stream)
 
     def nms(self, boxes, conf, score_threshold, iou_threshold, max_boxes, max_candidates=None,
-            want_class_candidates=False, _auto=False):
+            want_class_candidates=False, _auto=False, outputs=None, stream_events=None):
         """Score filter + per-class NMS on decoded inputs (YOLOv3.py:351-368).
-        boxes [B,N,4], conf [B,N,C] float32 CUDA tensors."""
+        boxes [B,N,4], conf [B,N,C] float32 CUDA tensors.  outputs, stream_events: as in detect()
+        (the events bracket the pass over the confidence matrix)."""
         lib = _abi.load()
         if boxes.device.type != 'cuda' or conf.device != boxes.device:
             raise RuntimeError('boxes and conf must live on one HIP device; there is no CPU path')
@@ -305,13 +306,17 @@ class DetectionHead:
         nbytes = ctypes.c_size_t(0)
         _abi.check(lib.yh_nms_workspace_bytes(B, N, C, cap, int(max_boxes), ctypes.byref(nbytes)))
         ws = self._workspace(('nms', B, N, cap, int(max_boxes)), nbytes.value, dev)
-        count, scores, oboxes, cls, idx, cc, status = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
+        if outputs is None:
+            outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
+        count, scores, oboxes, cls, idx, cc, status = outputs
+        args = [B, N, C, boxes.data_ptr(), conf.data_ptr(), float(score_threshold), float(iou_threshold),
+                int(max_boxes), cap, ws.data_ptr(), ws.numel()] + self._output_pointers(outputs) + [self._stream(dev)]
         with torch.cuda.device(dev):
-            _abi.check(lib.yh_nms(B, N, C, boxes.data_ptr(), conf.data_ptr(), float(score_threshold),
-                                  float(iou_threshold), int(max_boxes), cap, ws.data_ptr(), ws.numel(),
-                                  count.data_ptr(), scores.data_ptr(), oboxes.data_ptr(), cls.data_ptr(),
-                                  idx.data_ptr(), cc.data_ptr() if cc is not None else None,
-                                  status.data_ptr(), self._stream(dev)))
+            if stream_events is None:
+                _abi.check(lib.yh_nms(*args))
+            else:
+                _abi.check(lib.yh_nms_timed(*args, ctypes.c_void_p(stream_events[0].cuda_event),
+                                            ctypes.c_void_p(stream_events[1].cuda_event)))
         rerun = None
         if cap < full:
             auto = _auto or max_candidates is None

@@ -576,9 +576,15 @@ constexpr int kRowsBatch = 4 * kRowsTurns;    // survivors worked on together
 constexpr int kRowsAhead = 4;                 // steps whose objectness logits are requested together (a round)
 constexpr int kRowsList = 128;                // ring of queued survivors per wavefront (a step adds <= 64 to < kRowsBatch)
 constexpr int kRowsX = 6;                     // class logits per lane and row held in registers: 16 * 6 = 96 classes
-constexpr size_t kRowsLds = (size_t)kRowsWaves * ((size_t)kWaveStage * (16 + 8) + (size_t)kRowsList * 8);
+constexpr int kRowsPend = 64;                 // class logits past the prefilter, collected before the exact test: one per lane
+constexpr int kRowsStage = 64;                // candidates (key, box) staged per wavefront before they are written out
+// per wavefront: staged boxes and keys, the survivors' ring (row, objectness), the pending class logits
+// (16 bytes each) and the box channels of the batch's sixteen rows
+constexpr size_t kRowsLdsWave = (size_t)kRowsStage * (16 + 8) + (size_t)kRowsList * 8 + (size_t)kRowsPend * 16 + (size_t)kRowsBatch * 16;
+constexpr size_t kRowsLds = (size_t)kRowsWaves * kRowsLdsWave;
 static_assert(kRowsLds <= kRowsLdsMax, "the select stage riding in the launch is planned against kRowsLdsMax");
 static_assert((kRowsList & (kRowsList - 1)) == 0 && kRowsList >= 64 + kRowsBatch, "ring indices are masked");
+static_assert(kRowsLdsWave % 16 == 0, "every wavefront's block starts 16-byte aligned");
 
 __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams p, const NmsParams q)
 {
@@ -587,13 +593,21 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
         post_image_dyn<kRowsThreads>(q, (int)blockIdx.x, s_dyn);
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 *s_box = reinterpret_cast<float4 *>(s_dyn) + wave * kWaveStage;
-    unsigned char *at = s_dyn + (size_t)kRowsWaves * kWaveStage * 16;
-    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(at) + wave * kWaveStage;
-    at += (size_t)kRowsWaves * kWaveStage * 8;
-    uint32_t *s_lrow = reinterpret_cast<uint32_t *>(at) + wave * kRowsList;             // row inside the scale
-    float *s_lobj = reinterpret_cast<float *>(at + (size_t)kRowsWaves * kRowsList * 4) + wave * kRowsList;
+    // the wavefront's number as a scalar: the unit, its scale and every address derived from them then live in
+    // scalar registers, and the scale's parameters are scalar loads of the kernel arguments (a per-lane
+    // number makes them a vector load from memory, one more round trip before the first objectness read)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *at = s_dyn + (size_t)wave * kRowsLdsWave;
+    float4 *s_box = reinterpret_cast<float4 *>(at);
+    at += (size_t)kRowsStage * 16;
+    uint4 *s_pend = reinterpret_cast<uint4 *>(at);             // class logit, objectness logit, row, class | batch slot << 16
+    at += (size_t)kRowsPend * 16;
+    float4 *s_tb = reinterpret_cast<float4 *>(at);             // t_y, t_x, t_h, t_w of the batch's rows, by batch slot
+    at += (size_t)kRowsBatch * 16;
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(at);
+    at += (size_t)kRowsStage * 8;
+    uint32_t *s_lrow = reinterpret_cast<uint32_t *>(at);       // row inside the scale
+    float *s_lobj = reinterpret_cast<float *>(at + (size_t)kRowsList * 4);
 
     const uint32_t g = blockIdx.x - (uint32_t)q.B;
     const int b = (int)(g / p.units);                         // p.units: workgroups per image
@@ -624,6 +638,7 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     o.cand_cap = p.cand_cap;
     int count = 0;                                            // staged candidates, wave-uniform
     int emitted = 0;                                          // candidates of this unit already written out
+    int npend = 0;                                            // pending class logits, wave-uniform
     int head = 0, tail = 0;                                   // the survivors' ring: entries [head, tail), indices masked
     unsigned long long trB = 0, trC = 0;                      // measurement build: the last batch's data arrived / worked on
     (void)trB; (void)trC;
@@ -632,6 +647,42 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     // rows outside the unit read as NaN: no comparison with the prefilter (-inf for thr <= 0) holds for them
     const float kNoRow = __builtin_nanf("");
     auto objectness = [&](uint32_t row) { return row < row_end ? img[(size_t)row * K + C + 4] : kNoRow; };
+
+    // The exact test of the pending class logits, one per lane: sigmoid product against the threshold, and
+    // for those that pass the box of their row and the key, staged for the write-out.  A wavefront that
+    // found a few logits past the prefilter in a batch of rows pays this once, not once per row.
+    auto settle = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        const bool live = lane < npend;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (live) e = s_pend[lane];
+        const float cf = decode_sigmoid(__uint_as_float(e.x)) * decode_sigmoid(__uint_as_float(e.y));
+        const bool hit = live && cf >= thr;
+        const unsigned long long hm = __ballot(hit);
+        npend = 0;
+        if (hm == 0ull) return;
+        const int add = __builtin_popcountll(hm);
+        if (count + add > kRowsStage) wave_flush(o, s_keys, s_box, count, emitted, lane);
+        if (hit) {
+            const float4 tb = s_tb[e.w >> 16];
+            const int pos = count + __builtin_popcountll(hm & lanes_below);
+            s_keys[pos] = make_key((int)(e.w & 0xffffu), cf, (int)(sc.row_base + e.z));
+            s_box[pos] = decode_box(p.P, sc, tb.x, tb.y, tb.z, tb.w, e.z);
+        }
+        count += add;
+    };
+    // Queues the lanes' class logits that passed the prefilter (hit: this lane has one, x of class c, in
+    // the row of batch slot `slot` with objectness logit ob).
+    auto pend = [&](bool hit, int c, float x, float ob, uint32_t row, int slot) {
+        const unsigned long long hm = __ballot(hit);
+        if (hm == 0ull) return;
+        const int add = __builtin_popcountll(hm);
+        if (npend + add > kRowsPend) settle();
+        if (hit)
+            s_pend[npend + __builtin_popcountll(hm & lanes_below)] =
+                make_uint4(__float_as_uint(x), __float_as_uint(ob), row, (uint32_t)c | ((uint32_t)slot << 16));
+        npend += add;
+    };
 
     // Works on the first n (1 .. kRowsBatch) queued survivors.  Every row read here was queued by this
     // wavefront from a row < row_end of its own image and scale.
@@ -663,60 +714,32 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
 #pragma unroll
         for (int t = 0; t < kRowsTurns; ++t) {
             if (4 * t >= n) break;
-            const float so = decode_sigmoid(ob[t]);
-            const float *rp = img + (size_t)rw[t] * K;
-            const int nrow = (int)(sc.row_base + rw[t]);
-            // exact test of the classes held in registers: a bit per class that is a candidate
-            float cfv[kRowsX];
+            const int slot = 4 * t + grp;
+            if (val[t] && j < 4) reinterpret_cast<float *>(s_tb + slot)[j] = tb[t];
+            // a bit per class held in registers whose logit can still reach the threshold
             uint32_t bits = 0u;
 #pragma unroll
-            for (int i = 0; i < kRowsX; ++i) {
-                const float x = xv[t][i];
-                cfv[i] = decode_sigmoid(x) * so;
-                if (val[t] && j + 16 * i < C && x >= pf && cfv[i] >= thr) bits |= 1u << i;
-            }
-            bool have_box = false;                            // wave-uniform
-            float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-            // stages the lanes' candidates (hit: this lane has one, of class c with confidence cf)
-            auto emit = [&](bool hit, int c, float cf) {
-                const unsigned long long hm = __ballot(hit);
-                if (!have_box) {                              // the box of each group's row, in every lane of the group
-                    const int base = lane & 48;
-                    box = decode_box(p.P, sc, __shfl(tb[t], base, 64), __shfl(tb[t], base + 1, 64),
-                                     __shfl(tb[t], base + 2, 64), __shfl(tb[t], base + 3, 64), rw[t]);
-                    have_box = true;
-                }
-                if (hit) {
-                    const int pos = count + __builtin_popcountll(hm & lanes_below);
-                    s_keys[pos] = make_key(c, cf, nrow);
-                    s_box[pos] = box;
-                }
-                count += __builtin_popcountll(hm);
-                if (count >= 64) wave_flush(o, s_keys, s_box, count, emitted, lane);
-            };
-            while (__ballot(bits != 0u) != 0ull) {            // a lane's candidates one at a time: mostly one turn of this loop
+            for (int i = 0; i < kRowsX; ++i)
+                if (val[t] && j + 16 * i < C && xv[t][i] >= pf) bits |= 1u << i;
+            while (__ballot(bits != 0u) != 0ull) {            // a lane's logits one at a time: mostly one turn of this loop
                 const bool hit = bits != 0u;
                 const int i = hit ? __builtin_ctz(bits) : 0;
-                float cf = cfv[0];
+                float x = xv[t][0];
 #pragma unroll
-                for (int k = 1; k < kRowsX; ++k) cf = i == k ? cfv[k] : cf;
-                emit(hit, j + 16 * i, cf);
+                for (int k = 1; k < kRowsX; ++k) x = i == k ? xv[t][k] : x;
+                pend(hit, j + 16 * i, x, ob[t], rw[t], slot);
                 bits &= bits - 1u;
             }
-            for (int c0 = 16 * kRowsX; c0 < C; c0 += 16) {    // more classes than the registers hold
-                const int c = c0 + j;
-                bool hit = false;
-                float cf = 0.0f;
-                if (val[t] && c < C) {
-                    const float x = rp[c];
-                    if (x >= pf) {
-                        cf = decode_sigmoid(x) * so;
-                        hit = cf >= thr;
-                    }
+            if (16 * kRowsX < C) {                            // more classes than the registers hold
+                const float *rp = img + (size_t)rw[t] * K;
+                for (int c0 = 16 * kRowsX; c0 < C; c0 += 16) {
+                    const int c = c0 + j;
+                    const float x = val[t] && c < C ? rp[c] : kNoRow;
+                    pend(x >= pf, c, x, ob[t], rw[t], slot);
                 }
-                if (__ballot(hit) != 0ull) emit(hit, c, cf);
             }
         }
+        if (npend > 0) settle();                              // s_tb belongs to this batch
         head += n;
         YH_TRACE_NOW(trC);
     };
@@ -724,45 +747,67 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
     // A round is kRowsAhead steps whose objectness logits are requested together; the next round's are
     // in flight while this round's are looked at.  Launch plans aim at one round per unit, with every
     // workgroup of the launch resident: no wavefront then waits for a second memory round trip before
-    // its survivors' gathers.
+    // its survivors' gathers.  One more pass of the loop, after the last round, works the ring empty:
+    // written this way the batch code exists once in the kernel.
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
     (void)tr0; (void)tr1; (void)tr2; (void)tr3; (void)tr4;
+    int trace_left = 0;
+    (void)trace_left;
     YH_TRACE_NOW(tr0);
     float obj_n[kRowsAhead];
 #pragma unroll
     for (int k = 0; k < kRowsAhead; ++k)
         obj_n[k] = (uint32_t)k < nsteps ? objectness(row_begin + (uint32_t)k * 64u + (uint32_t)lane) : kNoRow;
-    for (uint32_t t = 0; t < nsteps; t += kRowsAhead) {
+    for (uint32_t t = 0;; t += kRowsAhead) {
+        const bool last = t >= nsteps;                        // wave-uniform
         float obj_c[kRowsAhead];
+        unsigned long long masks[kRowsAhead];
 #pragma unroll
         for (int k = 0; k < kRowsAhead; ++k) {
             obj_c[k] = obj_n[k];
-            const uint32_t tn = t + (uint32_t)(kRowsAhead + k);
-            obj_n[k] = tn < nsteps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
+            masks[k] = 0ull;
         }
+        if (!last) {
 #pragma unroll
-        for (int k = 0; k < kRowsAhead; ++k) {
-            const unsigned long long mask = __ballot(obj_c[k] >= pf);
+            for (int k = 0; k < kRowsAhead; ++k) {
+                const uint32_t tn = t + (uint32_t)(kRowsAhead + k);
+                obj_n[k] = tn < nsteps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
+            }
+#pragma unroll
+            for (int k = 0; k < kRowsAhead; ++k) masks[k] = __ballot(obj_c[k] >= pf);
 #ifdef YH_ROWS_TRACE
-            if (t == 0 && k == 0) { asm volatile("" ::"s"(mask)); YH_TRACE_NOW(tr1); }
+            if (t == 0) { asm volatile("" ::"s"(masks[0])); YH_TRACE_NOW(tr1); }
 #endif
-            if (mask) {
-                if ((mask >> lane) & 1ull) {
-                    const int e = (tail + __builtin_popcountll(mask & lanes_below)) & (kRowsList - 1);
-                    s_lrow[e] = row_begin + (t + (uint32_t)k) * 64u + (uint32_t)lane;
-                    s_lobj[e] = obj_c[k];
+        } else {
+            YH_TRACE_STAMP(tr2);
+            trace_left = tail - head;
+        }
+#pragma unroll 1
+        for (int k = 0; k < (last ? 1 : kRowsAhead); ++k) {
+            if (!last) {
+                unsigned long long mask = masks[0];
+                float ob = obj_c[0];
+#pragma unroll
+                for (int i = 1; i < kRowsAhead; ++i) {
+                    mask = k == i ? masks[i] : mask;
+                    ob = k == i ? obj_c[i] : ob;
                 }
-                tail += __builtin_popcountll(mask);
+                if (mask) {
+                    if ((mask >> lane) & 1ull) {
+                        const int e = (tail + __builtin_popcountll(mask & lanes_below)) & (kRowsList - 1);
+                        s_lrow[e] = row_begin + (t + (uint32_t)k) * 64u + (uint32_t)lane;
+                        s_lobj[e] = ob;
+                    }
+                    tail += __builtin_popcountll(mask);
+                }
             }
             // mid-walk only when the ring could not take another step: a batch waits for its gathers, which
             // queue behind whatever objectness reads are still outstanding
-            while (tail - head > kRowsList - 64) work(kRowsBatch);
+            const int keep = last ? 0 : kRowsList - 64;
+            while (tail - head > keep) work(tail - head < kRowsBatch ? tail - head : kRowsBatch);
         }
+        if (last) break;
     }
-    YH_TRACE_STAMP(tr2);
-    const int trace_left = tail - head;
-    (void)trace_left;
-    while (tail - head > 0) work(tail - head < kRowsBatch ? tail - head : kRowsBatch);
     YH_TRACE_STAMP(tr3);
     if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
     if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots

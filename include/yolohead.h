@@ -90,7 +90,11 @@ const char *yh_last_error(void);
  *                   (default 8), anything else = workgroup tiles;
  *   stream_buffers  wave-private tiles in flight per wavefront, 2..4 (default 3);
  *   stream_units    wave-private variant: target number of work units per launch;
- *   stream_blocks   workgroup-tile variant: target number of workgroups. */
+ *   stream_blocks   workgroup-tile variant: target number of workgroups' worth of
+ *                   tiles the pass is cut into;
+ *   stream_resident workgroup-tile variant: workgroups launched per compute unit,
+ *                   each walking the cuts in turn (default: one workgroup per
+ *                   cut, as many launched as there are cuts). */
 typedef struct yh_tuning {
     int32_t detect_kernel;
     int32_t row_steps;
@@ -98,6 +102,7 @@ typedef struct yh_tuning {
     int32_t stream_buffers;
     int32_t stream_units;
     int32_t stream_blocks;
+    int32_t stream_resident;
 } yh_tuning;
 int yh_set_tuning(const yh_tuning *tuning);   /* NULL restores the defaults */
 int yh_get_tuning(yh_tuning *tuning);

@@ -179,14 +179,16 @@ constexpr uint64_t kRowsResidentGroups = 512;   // objectness-first variant: two
 
 // Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
 // relaxed atomics; 0 = the built-in default.
-std::atomic<int32_t> g_tuning[6];
-enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks };
+std::atomic<int32_t> g_tuning[7];
+enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks, kTuneStreamResident };
 
 long knob(int which, long fallback)
 {
     const long v = g_tuning[which].load(std::memory_order_relaxed);
     return v > 0 ? v : fallback;
 }
+
+int compute_units();
 
 uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t max_candidates = 0)
 {
@@ -290,6 +292,10 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         p.sc[s].blk_begin = blocks;
         blocks += (uint32_t)chunks * (uint32_t)B;
     }
+    p.cuts = blocks;
+    p.grid_blocks = blocks;
+    const uint64_t resident = (uint64_t)knob(kTuneStreamResident, 0) * (uint64_t)compute_units();
+    if (resident > 0 && resident < blocks) p.grid_blocks = (uint32_t)resident;
     return blocks;
 }
 
@@ -352,11 +358,12 @@ int yh_version(void) { return 200; }
 
 int yh_set_tuning(const yh_tuning *t)
 {
-    const int32_t v[6] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
-                          t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0};
-    for (int i = 0; i < 6; ++i)
+    const int32_t v[7] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
+                          t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0,
+                          t ? t->stream_resident : 0};
+    for (int i = 0; i < 7; ++i)
         if (v[i] < 0) return fail(YH_ERR_INVALID_ARG, "tuning field %d is negative", i);
-    for (int i = 0; i < 6; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
+    for (int i = 0; i < 7; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
     return YH_OK;
 }
 
@@ -369,6 +376,7 @@ int yh_get_tuning(yh_tuning *t)
     t->stream_buffers = g_tuning[kTuneStreamNbuf].load(std::memory_order_relaxed);
     t->stream_units = g_tuning[kTuneStreamUnits].load(std::memory_order_relaxed);
     t->stream_blocks = g_tuning[kTuneStreamBlocks].load(std::memory_order_relaxed);
+    t->stream_resident = g_tuning[kTuneStreamResident].load(std::memory_order_relaxed);
     return YH_OK;
 }
 

@@ -98,6 +98,9 @@ struct StreamParams {
     int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
     uint32_t units;         // objectness-first variant: workgroups per image (eight units each)
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
+    uint32_t cuts;          // workgroup-tile variant: runs of tiles the pass is cut into (a workgroup's worth each)
+    uint32_t grid_blocks;   // workgroup-tile variant: workgroups launched; fewer than `cuts`: each walks cuts
+                            // blockIdx.x, blockIdx.x + gridDim.x, ...
     float thr;              // score threshold
     float prefilter;        // logits below this cannot reach thr
     int32_t cand_cap;

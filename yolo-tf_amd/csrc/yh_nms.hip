@@ -107,9 +107,11 @@ __device__ __forceinline__ void slice_range(const NmsParams &p, int b, int sub, 
     end = begin + kBinSlice < nl ? begin + kBinSlice : nl;
 }
 
+// The class tables of these kernels are dynamic LDS sized by the call's class count (launch_nms_pipeline):
+// a table for the largest class count the ABI admits would hold a compute unit to three such workgroups.
 __global__ __launch_bounds__(kBinSliceThreads) void k_bin_count(const NmsParams p, int slices)
 {
-    __shared__ int s_h[YH_MAX_CLASSES];
+    extern __shared__ int s_h[];             // [C]
     const int b = blockIdx.x / slices, sub = blockIdx.x - b * slices, tid = threadIdx.x, C = p.C;
     int begin, end, raw;
     slice_range(p, b, sub, begin, end, raw);
@@ -125,11 +127,12 @@ __global__ __launch_bounds__(kBinSliceThreads) void k_bin_count(const NmsParams 
 
 __global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParams p, int slices)
 {
-    __shared__ int s_cur[YH_MAX_CLASSES];    // histogram, then each segment's write cursor for this slice
-    __shared__ int s_end[YH_MAX_CLASSES];    // count, then each segment's end
-    __shared__ int s_mine[YH_MAX_CLASSES];   // this slice's histogram
+    extern __shared__ int s_tab[];           // [3][C]
     __shared__ int s_wave[kBinSliceThreads / 64];
     const int b = blockIdx.x / slices, sub = blockIdx.x - b * slices, tid = threadIdx.x, C = p.C, cap = p.cand_cap;
+    int *s_cur = s_tab;                      // histogram, then each segment's write cursor for this slice
+    int *s_end = s_tab + C;                  // count, then each segment's end
+    int *s_mine = s_tab + 2 * C;             // this slice's histogram
     int begin, end, raw;
     slice_range(p, b, sub, begin, end, raw);
     if (sub > 0 && begin >= end) return;
@@ -420,7 +423,7 @@ constexpr int kFinSlots = 4 * kFinThreads;   // slots per workgroup
 
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int parts)
 {
-    __shared__ int s_off[YH_MAX_CLASSES];
+    extern __shared__ int s_off[];           // [C]
     __shared__ int s_wave[kFinThreads / 64];
     const int b = blockIdx.x / parts, part = blockIdx.x - b * parts, tid = threadIdx.x, C = p.C, mb = p.max_boxes;
     const int32_t *kept = p.kept_cnt + (long long)b * C;
@@ -477,9 +480,9 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     if (p.upi == 0 && !p.boxes_fill && !p.cand_box && p.cand_cap > kBinSlice) {
         const int slices = (p.cand_cap + kBinSlice - 1) / kBinSlice;
         const dim3 grid((uint32_t)p.B * (uint32_t)slices);
-        hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinSliceThreads), 0, stm, p, slices);
+        hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinSliceThreads), (size_t)p.C * sizeof(int), stm, p, slices);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinSliceThreads), 0, stm, p, slices);
+        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinSliceThreads), (size_t)p.C * 3 * sizeof(int), stm, p, slices);
     } else {
         hipLaunchKernelGGL(k_bin, dim3(p.B), dim3(kBinThreads), 0, stm, p);
     }
@@ -490,7 +493,7 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int parts = (int)(((long long)p.C * p.max_boxes + kFinSlots - 1) / kFinSlots);
-    hipLaunchKernelGGL(k_finalize, dim3((uint32_t)p.B * (uint32_t)parts), dim3(kFinThreads), 0, stm, p, parts);
+    hipLaunchKernelGGL(k_finalize, dim3((uint32_t)p.B * (uint32_t)parts), dim3(kFinThreads), (size_t)p.C * sizeof(int), stm, p, parts);
     return hipGetLastError();
 }
 

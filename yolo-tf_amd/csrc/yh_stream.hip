@@ -129,12 +129,16 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wavefront's number, known to be uniform
     if (tid == 0) { st.count = 0; st.nhits = 0; }
 
+    // A cut is one workgroup's worth of tiles.  Launched with one workgroup per cut the hardware hands them
+    // out; launched with fewer (a fixed number per compute unit, so that LDS and wavefront slots stay free
+    // for another stream's kernels) every workgroup walks its cuts in turn.
+    for (uint32_t cut = blockIdx.x; cut < p.cuts; cut += gridDim.x) {
     int s = 0;
 #pragma unroll
     for (int i = 1; i < YH_MAX_SCALES; ++i)
-        if (i < p.S && blockIdx.x >= p.sc[i].blk_begin) s = i;
+        if (i < p.S && cut >= p.sc[i].blk_begin) s = i;
     const StreamScale &sc = p.sc[s];
-    const uint32_t r = blockIdx.x - sc.blk_begin;
+    const uint32_t r = cut - sc.blk_begin;
     const int b = (int)(r / sc.chunks_per_img);
     const uint32_t chunk = r - (uint32_t)b * sc.chunks_per_img;
 
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
     }
     __syncthreads();
     flush_candidates(st, p, b, st.count);
+    }
 }
 
 // ------------------------------------------------------------ wave-private variant
@@ -977,7 +982,8 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
         }
     }
     if (blocks == 0) return hipSuccess;
-    const dim3 grid(blocks), block(kThreads);
+    if (p.cuts != blocks || p.grid_blocks == 0 || p.grid_blocks > blocks) return hipErrorInvalidValue;
+    const dim3 grid(p.grid_blocks), block(kThreads);
     if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
     else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, 0, stm, p);
     return hipGetLastError();

@@ -452,9 +452,14 @@ def main():
     gc.disable()                                            # no collector pause inside the few-millisecond timed regions
     # Untimed priming, whatever W is: every lane's pipeline reaches its steady state (both workspaces
     # and output sets allocated, the prepared call of each slot built), and the host path is warm.
+    # In bursts closed by a synchronisation, like the timed regions: the first submits after the host
+    # thread has slept in a synchronisation take two to three times as long as the rest until that path
+    # has run a few times (25-30 us against 8), which a region of a few dozen steps would feel.
     last = None
-    for i in range(PRIME_STEPS):
-        step(i)
+    for burst in range(4):
+        for i in range(PRIME_STEPS // 4):
+            step(i)
+        barrier()
     for i in range(warmup):
         last = step(i)
     barrier()

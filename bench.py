@@ -326,6 +326,8 @@ def main():
                          '1 = one stream, launches back to back; default 3')
     ap.add_argument('--detect-kernel', type=int, default=0, choices=(0, 1, 2),
                     help='yh_set_tuning.detect_kernel: 0/1 = objectness-first rows kernel, 2 = streaming kernel')
+    ap.add_argument('--row-steps', type=int, default=0,
+                    help='yh_set_tuning.row_steps: steps of 64 rows per work unit of the rows kernel (0 = planned from the batch)')
     ap.add_argument('--stream-resident', type=int, default=0,
                     help='yh_set_tuning.stream_resident: workgroups of the tile kernel launched per compute unit (0 = one per cut)')
     ap.add_argument('--force-allreduce', action='store_true',
@@ -347,8 +349,8 @@ def main():
         raise SystemExit('bench.py needs a HIP device: the path has no CPU fallback')
     dev = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if args.detect_kernel or args.stream_resident:
-        y._abi.set_tuning(detect_kernel=args.detect_kernel, stream_resident=args.stream_resident)
+    if args.detect_kernel or args.stream_resident or args.row_steps:
+        y._abi.set_tuning(detect_kernel=args.detect_kernel, stream_resident=args.stream_resident, row_steps=args.row_steps)
 
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['batch']

@@ -85,7 +85,8 @@ const char *yh_last_error(void);
  * depends on cfg, batch, the bounds and this tuning, and on nothing else.
  *   detect_kernel   1: objectness-first rows kernel (default); 2: streaming
  *                   kernels that read the whole head;
- *   row_steps       rows kernel: steps of 64 rows per work unit (default 2);
+ *   row_steps       rows kernel: steps of 64 rows per work unit (default: the fewest
+ *                   with which the launch is resident at once, 2..16);
  *   stream_tile_kib streaming kernel: wave-private tiles of 4 or 8 KiB
  *                   (default 8), anything else = workgroup tiles;
  *   stream_buffers  wave-private tiles in flight per wavefront, 2..4 (default 3);

@@ -1,8 +1,8 @@
 """A/B timing of the streaming pass (yh_detect_candidates alone, one stream, back to back) between
-two builds of the library, interleaved in one process so that both see the same chip and clocks:
+builds of the library (two or more), interleaved in one process so that all see the same chip and clocks:
 config-2 shape at several row-survival rates (objectness ~ N(mu, 2), class logits too low for any
 candidate except at the benchmark's own distribution).
-usage: time_ab.py libA.so libB.so [row_steps for A] [row_steps for B]"""
+usage: time_ab.py libA.so libB.so [libC.so ...]   (AB_STEPS=n: row_steps for all)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -16,11 +16,11 @@ grids, priors, box_mult, gt_rate = bench.build_head(w)
 B, P, C = int(os.environ.get('AB_BATCH', w['batch'])), len(priors[0]), w['C']
 cfg = y.head.make_config(grids, priors, box_mult, gt_rate, C)
 libs = []
-for k, path in enumerate(sys.argv[1:3]):
+for k, path in enumerate(a for a in sys.argv[1:] if a.endswith('.so')):
     lib = ctypes.CDLL(os.path.abspath(path))
     for name in ('yh_detect_workspace_bytes', 'yh_detect_candidates', 'yh_set_tuning'):
         fn = getattr(lib, name); fn.restype, fn.argtypes = _abi.SIGNATURES[name]
-    steps = int(sys.argv[3 + k]) if len(sys.argv) > 3 + k else 0
+    steps = int(os.environ.get('AB_STEPS', 0))
     t = _abi.Tuning(row_steps=steps, stream_blocks=int(os.environ.get('AB_BLOCKS', 0)))
     assert lib.yh_set_tuning(ctypes.byref(t)) == 0
     libs.append((os.path.basename(path) + ('/steps%d' % steps if steps else ''), lib))

@@ -174,8 +174,13 @@ constexpr uint64_t kStreamTargetBlocks = 3600;
 // workgroup 945 us, 15: 904, 9: 883, 8: 877.
 constexpr uint64_t kStreamTilesPerBlock = 8;
 
-constexpr uint64_t kStreamTargetUnits = 8192;
-constexpr uint64_t kRowsResidentGroups = 512;   // objectness-first variant: two 512-thread workgroups on each of 256 compute units   // wave-private variant: work units (one per wavefront)
+constexpr uint64_t kStreamTargetUnits = 8192;    // wave-private variant: work units (one per wavefront)
+// Objectness-first variant: workgroups (four wavefronts each) a launch may hold and still be resident at once with
+// room to spare, three on each of 256 compute units.  (Measured at 64 images of 10647 boxes with the select stage
+// riding along: 512-thread workgroups, 512 of them: 23.8 us per launch alone, 17.2 us per step on three streams;
+// 256-thread workgroups: 768 -> 22.1 / 16.6 us, 1024 or 1280 -> 23.1 / 16.5 us; 128-thread workgroups 25.1 / 16.4 us,
+// the select stage's workgroup then being the launch's slowest.)
+constexpr uint64_t kRowsResidentGroups = 768;
 
 // Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
 // relaxed atomics; 0 = the built-in default.
@@ -211,7 +216,7 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
     }
     if (p.row_gather) {
         // a work unit = `steps` steps of 64 rows (one per lane) of one image and scale; a workgroup
-        // takes eight consecutive units of one image (the last workgroup of an image may hold spare
+        // takes four consecutive units of one image (the last workgroup of an image may hold spare
         // ones); an image's units are indexed by the candidates -> detections stage, so their
         // number is bounded
         const uint32_t waves = (uint32_t)(yh::kRowsThreads / 64);
@@ -221,7 +226,7 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
             return (upi + waves - 1) / waves * waves;
         };
         // Default: the fewest steps per unit (down to two) with which the whole launch is resident at once,
-        // two workgroups per compute unit, counting the select stage's workgroup per image that rides in
+        // three workgroups per compute unit, counting the select stage's workgroup per image that rides in
         // a pipelined launch (it holds its slot for about 12 us): a unit of up to four steps asks for all
         // its objectness logits at the start, and no workgroup waits for a slot before it can ask.
         uint64_t steps = (uint64_t)knob(kTuneRowSteps, 0);

@@ -96,7 +96,7 @@ struct StreamParams {
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
     int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
-    uint32_t units;         // objectness-first variant: workgroups per image (eight units each)
+    uint32_t units;         // objectness-first variant: workgroups per image (kRowsThreads / 64 units each)
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     uint32_t cuts;          // workgroup-tile variant: runs of tiles the pass is cut into (a workgroup's worth each)
     uint32_t grid_blocks;   // workgroup-tile variant: workgroups launched; fewer than `cuts`: each walks cuts
@@ -187,7 +187,7 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
 bool select_single_launch(int cand_cap, int num_classes, int max_boxes);   // k_post takes the whole stage
 bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
 bool select_fits_rows(const NmsParams &p);     // ... in a launch of the objectness-first variant
-constexpr int kRowsThreads = 512;           // objectness-first variant: eight wavefronts per workgroup
+constexpr int kRowsThreads = 256;           // objectness-first variant: four wavefronts per workgroup
 constexpr size_t kRowsLdsMax = 40 * 1024;   // four such workgroups per compute unit
 
 // ---- loss ------------------------------------------------------------------

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
 // few-percent survival rate of a detector's head, most of the tensor need not be read at all.
 //
 // A wavefront owns one work unit: `steps` steps of 64 rows of one image and scale, and walks
-// them on its own (a workgroup is eight such wavefronts on consecutive units of one image and
+// them on its own (a workgroup is four such wavefronts on consecutive units of one image and
 // has no barrier).  Per step:
 //   1. a lane reads the objectness logit of one row (one float per K: the memory system
 //      fetches a 128-byte line per row instead of the row); the next step's logits are
@@ -576,7 +576,7 @@ __device__ unsigned long long g_rows_trace[kTraceWaves * kTraceWords];
 #endif
 
 constexpr int kRowsWaves = kRowsThreads / 64;
-constexpr int kRowsTurns = 4;                 // turns of four rows whose loads are in flight together
+constexpr int kRowsTurns = 4;                 // turns of four rows whose loads are in flight together (six or eight: no faster)
 constexpr int kRowsBatch = 4 * kRowsTurns;    // survivors worked on together
 constexpr int kRowsAhead = 4;                 // steps whose objectness logits are requested together (a round)
 constexpr int kRowsList = 128;                // ring of queued survivors per wavefront (a step adds <= 64 to < kRowsBatch)

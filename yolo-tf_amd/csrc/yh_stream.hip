@@ -551,11 +551,12 @@ __global__ __launch_bounds__(64) void k_stream_wave(const StreamParams p, const 
 //      fetches a 128-byte line per row instead of the row); the next step's logits are
 //      requested before this step's are looked at;
 //   2. the rows that pass are appended to the wavefront's ring of survivors in LDS;
-//   3. whenever kRowsBatch survivors are queued (and once more at the end of the unit) they
-//      are worked on together: sixteen lanes per row, four rows per turn, the loads of all
-//      kRowsTurns turns in flight at once (a lane holds kRowsX class logits of its row per turn),
-//      exact sigmoid product and threshold test, box decode once per row with a hit,
-//      (key, box) staged per wavefront.
+//   3. when the ring could not take another step (and at the end of the unit) the queued rows are
+//      worked on in batches of kRowsBatch: sixteen lanes per row, four rows per turn, the loads of all
+//      kRowsTurns turns in flight at once (a lane holds kRowsX class logits of its row per turn); a
+//      turn only compares its logits with the prefilter and queues those that pass; one pass per
+//      batch, a lane per queued logit, does the exact sigmoid product and threshold test, decodes the
+//      box and stages (key, box) per wavefront.
 // How much is in flight is what matters: with every row of the launch requested at once (one
 // row per lane and everything resident) a survivor's gather queues behind the whole objectness
 // column, so the launch becomes column phase, then gather phase, then stores, each waiting for
@@ -578,7 +579,11 @@ __device__ unsigned long long g_rows_trace[kTraceWaves * kTraceWords];
 constexpr int kRowsWaves = kRowsThreads / 64;
 constexpr int kRowsTurns = 4;                 // turns of four rows whose loads are in flight together (six or eight: no faster)
 constexpr int kRowsBatch = 4 * kRowsTurns;    // survivors worked on together
-constexpr int kRowsAhead = 4;                 // steps whose objectness logits are requested together (a round)
+// Steps whose objectness logits are requested together (a round).  One: a wavefront has this step's and the
+// next step's logits in flight, 128 lines.  (64 images of 10647 boxes, four steps per unit, per launch alone /
+// per step on three streams: 4 -> 22.1 / 16.6 us, 3 -> 21.4 / 16.6, 2 -> 21.2 / 16.5, 1 -> 20.8 / 16.4; 22743
+// boxes per image, nine steps per unit: 4 -> 43.8 / 34.9, 2 -> 41.7 / 34.8, 1 -> 42.1 / 34.8.)
+constexpr int kRowsAhead = 1;
 constexpr int kRowsList = 128;                // ring of queued survivors per wavefront (a step adds <= 64 to < kRowsBatch)
 constexpr int kRowsX = 6;                     // class logits per lane and row held in registers: 16 * 6 = 96 classes
 constexpr int kRowsPend = 64;                 // class logits past the prefilter, collected before the exact test: one per lane

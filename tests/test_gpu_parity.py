@@ -354,6 +354,25 @@ def test_streaming_variants_agree(gpu, tuning, obj_mean, hot_mean):
         assert torch.equal(got.class_candidates, want_cc)
 
 
+def test_tile_kernel_with_a_fixed_number_of_workgroups(gpu, tuning):
+    """yh_tuning.stream_resident: the workgroup-tile kernel launched as one workgroup per compute unit,
+    each walking several runs of tiles (446 runs here), against one workgroup per run."""
+    case = cases.stress(grid=40)
+    dheads = to_dev(case.heads(78, 2, **y.synth.STRESS), gpu)
+    cap = 40000
+    ref = case.head_obj().detect(dheads, 0.001, 0.5, 100, max_candidates=cap, want_class_candidates=True)
+    assert not ref.overflowed() and int(ref.count.sum()) > 0
+    want, want_cc = ref.per_image(), ref.class_candidates.clone()
+    for blocks, resident in ((100000, 1), (100000, 2), (300, 1)):
+        tuning(stream_blocks=blocks, stream_resident=resident)
+        got = case.head_obj().detect(dheads, 0.001, 0.5, 100, max_candidates=cap, want_class_candidates=True)
+        assert not got.overflowed()
+        cases.same_detections(got.per_image(), want)
+        for a, b in zip(got.per_image(), want):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert torch.equal(got.class_candidates, want_cc)
+
+
 def test_rows_wider_than_a_wave_tile(gpu):
     """2100 classes: one row (8420 B) does not fit the wave-private tiles, the
     workgroup-tile kernel takes over; 600 classes: several 64-lane passes per row."""

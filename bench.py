@@ -575,7 +575,8 @@ def main():
                            note='region 0 is the one value / ms_per_step report; every region is %d steps between '
                                 'barriers' % steps),
         }
-        rec = load_traffic(args.workload, kname)
+        # the committed counter passes are of the workload's own batch
+        rec = load_traffic(args.workload, kname) if B == w['batch'] else None
         if rec and w.get('backward'):                       # the call's second launch
             rec2 = load_traffic(args.workload, 'k_loss_grad_pos')
             if rec2:
@@ -589,8 +590,8 @@ def main():
         res['roofline'] = dict(
             bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
             traffic=int(traffic) if traffic is not None else None,
-            traffic_source=(rec.get('source') if rec else 'no committed PMC pass for this (workload, kernel): achieved / frac '
-                                                           'price traffic_model instead'),
+            traffic_source=(rec.get('source') if rec else 'no committed PMC pass for this (workload, kernel, batch): achieved / '
+                                                           'frac price traffic_model instead'),
             traffic_model=int(model), kernel=kdesc, kernel_key=kname, kernel_ms=round(kern_ms, 5),
             kernel_ms_runs=[round(r, 5) for r in kern_runs], kernel_timing=timing,
             algorithmic_bytes_per_launch=int(algo), algorithmic_gbs=round(algo / (kern_ms * 1e-3) / 1e9, 1),

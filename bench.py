@@ -406,11 +406,26 @@ def main():
     pipe = None
     nstreams = 1
     if w['kind'] == 'nms':
+        # yh_nms calls of consecutive batches go to streams of their own in turn (--streams, default 3), each with
+        # its own head object (workspace) and outputs: the select stage's launches of one batch run beside the
+        # pass over the next batch's confidence matrix, as in the stress workload
         outputs = hd._alloc_outputs(B, w['max_boxes'], dev, False)
+        nstreams = max(1, args.streams or 3)
+        nms_lanes = []
+        for _ in range(nstreams):
+            lane_hd = y.DetectionHead(C, priors, box_mult, gt_rate)
+            lane_st = torch.cuda.Stream(dev)
+            with torch.cuda.stream(lane_st):
+                lane_hd.nms(decoded[0][0], decoded[0][1], w['thr'], w['iou'], w['max_boxes']).resolved()
+            nms_lanes.append((lane_st, lane_hd, hd._alloc_outputs(B, w['max_boxes'], dev, False)))
+        torch.cuda.synchronize(dev)
+        extra.update(streams=nstreams)
 
         def step(i):
             bx, cf = decoded[i % rotate]
-            return hd.nms(bx, cf, w['thr'], w['iou'], w['max_boxes'], outputs=outputs)
+            lane_st, lane_hd, lane_out = nms_lanes[i % nstreams]
+            with torch.cuda.stream(lane_st):
+                return lane_hd.nms(bx, cf, w['thr'], w['iou'], w['max_boxes'], outputs=lane_out)
     elif w['kind'] == 'detect':
         # Software pipeline over the sequence of batches, as a serving loop would run the path: a
         # step streams batch i and, inside the same launch, selects batch i-1 (yh_detect_pipelined).

@@ -164,15 +164,20 @@ int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_
 }
 
 // Fills the per-scale block decomposition of the streaming pass.  A workgroup
-// walks tiles of whole rows (<= 24 KiB each) and ends with a latency-bound tail
+// walks tiles of whole rows (<= 16 KiB each) and ends with a latency-bound tail
 // (the atomic that reserves its candidate range), so the launch is
 // oversubscribed: about kStreamTargetBlocks workgroups, a few per resident slot.
 constexpr uint64_t kStreamTargetBlocks = 3600;
 // Few tiles per workgroup: what a workgroup stages then leaves in one flush at its end (a flush is a
 // round trip to the image's candidate counter with the whole workgroup waiting), and the launch ends
-// without a long tail.  128 images of 100x100x10 boxes, 80 classes, one candidate per box: 48 tiles per
-// workgroup 945 us, 15: 904, 9: 883, 8: 877.
-constexpr uint64_t kStreamTilesPerBlock = 8;
+// without a long tail.  128 images of 100x100x10 boxes, 80 classes, one candidate per box, 16 KiB tiles,
+// pass on its own / step with the select stages of other batches beside it: 3 tiles per workgroup
+// 1108 / 1257 us, 4: 973 / 1247, 5: 921 / 1251, 6: 916 / 1184, 7: 923 / 1224, 8: 940 / 1243, 10: 981 / 1229,
+// 12: 946 / 1236, 16: 957 / 1259.
+constexpr uint64_t kStreamTilesPerBlock = 6;
+// The confidence matrix of yh_nms (no decode, rows of C floats, its launches on one stream): 8 tiles per workgroup
+// 786 us for 128 images of 1e5 x 80 confidences, 6 tiles 810 us.
+constexpr uint64_t kStreamTilesPerBlockConf = 8;
 
 constexpr uint64_t kStreamTargetUnits = 8192;    // wave-private variant: work units (one per wavefront)
 // Objectness-first variant: workgroups (four wavefronts each) a launch may hold and still be resident at once with
@@ -284,7 +289,8 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
     // tuning knob; by default at least kStreamTargetBlocks workgroups and at most kStreamTilesPerBlock tiles each
     uint64_t want = (uint64_t)knob(kTuneStreamBlocks, 0);
-    if (want == 0) want = std::max<uint64_t>(kStreamTargetBlocks, total_tiles / kStreamTilesPerBlock);
+    if (want == 0)
+        want = std::max<uint64_t>(kStreamTargetBlocks, total_tiles / (mode == yh::kModeConf ? kStreamTilesPerBlockConf : kStreamTilesPerBlock));
     uint64_t tpc = (total_tiles + want / 2) / want;              // tiles per workgroup, nearest
     if (tpc < 1) tpc = 1;
     if (tpc > 64) tpc = 64;
@@ -310,7 +316,7 @@ void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, con
     p.S = cfg->num_scales; p.B = B; p.C = cfg->num_classes; p.P = cfg->num_priors;
     p.K = p.C + 5; p.N = (int32_t)boxes_per_image(cfg);
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
-    p.scan_col_step = 1024 % p.K;
+    p.scan_col_step = (4 * yh::kTileThreads) % p.K;
     uint32_t row_base = 0;
     for (int s = 0; s < p.S; ++s) {
         yh::StreamScale &sc = p.sc[s];
@@ -767,7 +773,7 @@ static int nms_impl(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     std::memset(&p, 0, sizeof(p));
     p.S = 1; p.B = batch; p.C = num_classes; p.P = 1; p.K = num_classes; p.N = (int32_t)boxes_per_img;
     p.magic_k = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.K) + 1u;
-    p.scan_col_step = 1024 % p.K;
+    p.scan_col_step = (4 * yh::kTileThreads) % p.K;
     p.thr = score_threshold;
     p.cand_cap = max_candidates;
     p.cand = w.cand;

@@ -91,7 +91,7 @@ struct StreamScale {
 struct StreamParams {
     int32_t S, B, C, P, K, N;
     uint32_t magic_k;       // floor(2^32 / K) + 1: row of a flat index by multiply-high (K >= 2)
-    int32_t scan_col_step;  // (floats a workgroup scans per step: 4 * 256) mod K
+    int32_t scan_col_step;  // (floats a workgroup scans per step: 4 * kTileThreads) mod K
     int32_t tile_rows;      // rows per LDS tile: floor((tile floats - 3) / K)
     int32_t wave_ni;        // 0: workgroup tiles of kTileFloats; 4 or 8: wave-private tiles of wave_ni KiB
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
@@ -120,7 +120,13 @@ constexpr size_t kLdsPerWorkgroupMax = 160 * 1024;   // LDS of one gfx950 comput
 
 hipError_t launch_probe_read(const void *src, size_t bytes, hipStream_t st);
 
-constexpr int kTileFloats = 6144;                   // LDS tile of the streaming pass: 24 KiB (of 16 to 32 KiB the fastest on the dense workload)
+// Workgroup-tile variant of the streaming pass: two wavefronts on a 16 KiB LDS tile.  On the dense workload (128 images of
+// 100x100x10 boxes, 80 classes, one candidate per box) four wavefronts on 24 KiB are 1 % faster for the pass on its own
+// (924 against 935 us), but the pass shares the chip with the select stage's kernels of the batches before it on other
+// streams, and the smaller workgroup leaves them LDS: 1.219 against 1.286 ms per step (12 / 20 KiB tiles 1.26 / 1.25 ms;
+// one wavefront on 8 KiB 1.40 ms).
+constexpr int kTileThreads = 128;
+constexpr int kTileFloats = 4096;
 
 enum StreamMode { kModeDetect = 0, kModeFull = 1, kModeConf = 2 };
 

@@ -3,7 +3,7 @@
 //
 // The NHWC head of one scale is a row-major matrix [B * rows_img][K], K = C + 5,
 // one row per box.  A workgroup walks tiles of whole rows of one image.  A tile
-// (up to 24 KiB) goes from HBM straight into LDS with LDS-DMA loads
+// (up to 16 KiB) goes from HBM straight into LDS with LDS-DMA loads
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination,
 // no VALU work), issued back to back so that the whole tile is in flight at
 // once; the 16-byte phase of the tile start is absorbed by an aligned window
@@ -35,7 +35,7 @@
 namespace yh {
 
 constexpr int kThreads = 256;
-constexpr int kStage = 768;      // candidate keys staged per workgroup
+constexpr int kStage = 512;      // candidate keys staged per workgroup
 constexpr int kHitCap = 512;     // class logits that passed the prefilter, collected before they are worked on
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -111,7 +111,7 @@ __device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &
         if (tid == 0) st.base = atomicAdd(&p.img_count[b], cnt);
         __syncthreads();
         const int base = st.base;
-        for (int i = tid; i < cnt; i += kThreads) {
+        for (int i = tid; i < cnt; i += kTileThreads) {
             const int g = base + i;
             if ((uint32_t)g < (uint32_t)p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
         }
@@ -122,7 +122,7 @@ __device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
+__global__ __launch_bounds__(kTileThreads) void k_stream(const StreamParams p)
 {
     __shared__ __attribute__((aligned(16))) Stage st;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         // scalar branches), the lane's address one 64-bit add away from a pointer computed once per tile
         const float4 *lane_src = src4 + q0 + lane;
 #pragma unroll
-        for (int j = 0; j < kTileFloats / 4 / kThreads; ++j) {
-            const int slot0 = (j * (kThreads / 64) + wave_u) * 64;
+        for (int j = 0; j < kTileFloats / 4 / kTileThreads; ++j) {
+            const int slot0 = (j * (kTileThreads / 64) + wave_u) * 64;
             if (slot0 + 64 <= ndma) {
                 __builtin_amdgcn_global_load_lds((gptr_t *)(lane_src + slot0), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
             } else if (slot0 < ndma) {                        // the window's last group: lanes past the end re-read the last slot
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         // ---- scan: every float of the window against the prefilter, 16 bytes per lane and step.
         // The scan is conservative and cheap: a float passes when it reaches the prefilter and its
         // column (float index mod K; the column of a lane's first float is kept up to date by
-        // adding (4 * kThreads) mod K per step) is not one of the K - C columns behind the class
+        // adding (4 * kTileThreads) mod K per step) is not one of the K - C columns behind the class
         // logits.  A lane with a hit leaves ONE entry (slot number and a bit per float) in the
         // list; the lanes then take the entries densely and the exact step sorts out what the
         // scan let through (floats outside the tile, columns that wrapped into the next row).
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         const uint32_t behind = (uint32_t)(K - C);            // columns C .. K-1 hold no class logit
         const int fi_first = 4 * tid - sh;                    // -3 .. -1: before the tile
         int col0 = fi_first >= 0 ? (K == 1 ? 0 : fi_first - (int)__umulhi((uint32_t)fi_first, p.magic_k) * K) : fi_first + K;
-        for (int w = tid; w < wslots; w += kThreads) {
+        for (int w = tid; w < wslots; w += kTileThreads) {
             const float4 v = reinterpret_cast<const float4 *>(st.tile)[w];
             const uint32_t t0 = (uint32_t)(col0 - C);
             uint32_t hit = (v.x >= pf && t0 >= behind) ? 1u : 0u;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void k_stream(const StreamParams p)
         }
         __syncthreads();
         const int nhits = st.nhits < kHitCap ? st.nhits : kHitCap;
-        for (int h = tid; h < nhits; h += kThreads) {
+        for (int h = tid; h < nhits; h += kTileThreads) {
             const uint32_t e = st.hits[h];
             exact_bits((int)(e & 0xFFFu), e >> 12);
         }
@@ -989,7 +989,7 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
     }
     if (blocks == 0) return hipSuccess;
     if (p.cuts != blocks || p.grid_blocks == 0 || p.grid_blocks > blocks) return hipErrorInvalidValue;
-    const dim3 grid(p.grid_blocks), block(kThreads);
+    const dim3 grid(p.grid_blocks), block(kTileThreads);
     if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
     else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, 0, stm, p);
     return hipGetLastError();

@@ -180,6 +180,21 @@ __global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParam
 // again: the result is that of the full sort in every case.
 constexpr int kSelMax = 1024;        // longest prefix sorted on its own
 
+// The prefix a call aims at, and the room its selection needs (a power of two: the prefix is sorted padded to
+// one; 0: the bounds do not allow a prefix, whole segments are sorted).  The room is dynamic LDS behind the
+// selected boxes, sized per call: 4 KiB at nms_max_boxes <= 204, so that more of these workgroups fit beside
+// another stream's kernels than with room for kSelMax keys in every launch.
+__host__ __device__ inline int prefix_target(int max_boxes) { return 2 * max_boxes > 240 ? 2 * max_boxes : 240; }
+__host__ __device__ inline int prefix_room(int max_boxes)
+{
+    const int target = prefix_target(max_boxes), most = target + (target >> 2);
+    if (most > kSelMax) return 0;
+    int room = 128;
+    while (room < most) room <<= 1;
+    return room;
+}
+__host__ __device__ inline size_t kept_boxes_bytes(int max_boxes) { return ((size_t)max_boxes * 5 * sizeof(float) + 15) & ~(size_t)15; }
+
 // Bins of s_hist -> the first bin at which the running count reaches `target`; wave 0 only.
 // Returns the bin, its inclusive running count in *cum; `before` is added to the counts.
 __device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before, int target, int *cum)
@@ -207,9 +222,9 @@ __device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before,
     return __builtin_amdgcn_readlane(found, src);
 }
 
-// Block-wide.  s_keys[0..cnt) -> s_sel[0..n): the n smallest keys for some n in [target, kSelMax],
+// Block-wide.  s_keys[0..cnt) -> s_sel[0..n): the n smallest keys for some n in [target, room],
 // unordered; returns n, or 0 when no such prefix exists at the two levels' resolution.
-__device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, int target,
+__device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, int target, int room,
                                     unsigned long long *s_sel, int *s_hist, int *s_ctl)
 {
     const int tid = threadIdx.x;
@@ -245,7 +260,7 @@ __device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, i
         n = s_ctl[1];
         __syncthreads();
     }
-    if (n > kSelMax) return 0;                              // s_sel holds kSelMax keys
+    if (n > room) return 0;                                 // s_sel holds `room` keys
     for (int i = tid; i < cnt; i += kSegThreads) {
         const unsigned long long k = s_keys[i];
         const int b1 = (int)(k >> kShift1) & 0xFF, b2 = (int)(k >> kShift2) & 0xFF;
@@ -331,9 +346,10 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, const f
 __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
 {
     __shared__ unsigned long long s_keys[kSortLds];
-    __shared__ unsigned long long s_sel[kSelMax];
-    extern __shared__ __align__(16) unsigned char s_dyn[];    // the selected boxes: max_boxes x 5 floats
+    extern __shared__ __align__(16) unsigned char s_dyn[];    // the selected boxes (max_boxes x 5 floats), then the prefix's keys
     float (*s_kbox)[5] = reinterpret_cast<float (*)[5]>(s_dyn);
+    unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(s_dyn + kept_boxes_bytes(p.max_boxes));
+    const int sel_room = prefix_room(p.max_boxes);
     __shared__ int s_hist[kSegThreads];
     __shared__ int s_ctl[4];
     __shared__ BlockNmsLds s_walk;
@@ -386,9 +402,9 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         for (int i = tid; i < cnt; i += kSegThreads) s_keys[i] = keys[i];
         __syncthreads();
         // a prefix of about 240 keys sorts as 256 (the selection overshoots its target by a few keys)
-        const int target = 2 * p.max_boxes > 240 ? 2 * p.max_boxes : 240;
-        if (cnt >= 2 * target && target + (target >> 2) <= kSelMax) {
-            const int n = select_prefix(s_keys, cnt, target, s_sel, s_hist, s_ctl);
+        const int target = prefix_target(p.max_boxes);
+        if (cnt >= 2 * target && sel_room > 0) {
+            const int n = select_prefix(s_keys, cnt, target, sel_room, s_sel, s_hist, s_ctl);
             if (n > 0) {
                 int n2 = 128;
                 while (n2 < n) n2 <<= 1;
@@ -489,7 +505,7 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_sort_nms, dim3((uint32_t)p.B * (uint32_t)p.C), dim3(kSegThreads),
-                       (size_t)p.max_boxes * 5 * sizeof(float), stm, p);
+                       kept_boxes_bytes(p.max_boxes) + (size_t)prefix_room(p.max_boxes) * sizeof(unsigned long long), stm, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int parts = (int)(((long long)p.C * p.max_boxes + kFinSlots - 1) / kFinSlots);

@@ -354,6 +354,44 @@ def test_streaming_variants_agree(gpu, tuning, obj_mean, hot_mean):
         assert torch.equal(got.class_candidates, want_cc)
 
 
+@pytest.mark.parametrize('C,P,grid,share,cold', [(80, 3, 30, 0.01, 0.0), (97, 5, 24, 0.006, 1.0), (130, 3, 20, 0.015, -1.0),
+                                                 (20, 9, 26, 0.015, 0.5), (80, 3, 30, 0.1, -3.0), (80, 3, 30, 0.6, -3.0)])
+def test_rows_kernel_with_many_candidates_per_row(gpu, tuning, C, P, grid, share, cold):
+    """Few to many rows pass the objectness prefilter and most of their classes pass the score threshold: a
+    batch of sixteen rows then holds several hundred class logits for the exact test (more than its pending
+    list takes at once), a wavefront stages more candidates than its unit's private slots hold, and the
+    image's list takes the rest.  The objectness-first kernel (several unit lengths) against the staged path
+    (full decode, then the tile kernel over the confidence matrix) and against the oracle's candidate counts."""
+    rng = np.random.Generator(np.random.PCG64(7 + C))
+    priors = [rng.uniform(0.5, 3.0, size=(P, 2)).astype(np.float32)]
+    heads = y.synth.make_heads(300 + C, 2, [(grid, grid)], P, C, hot_mean=2.0, cold_mean=cold, cold_std=1.5)
+    K = C + 5
+    rows = heads[0].reshape(-1, K)
+    alive = rng.random(rows.shape[0]) < share
+    rows[:, K - 1] = np.where(alive, rng.normal(3.0, 1.0, rows.shape[0]), -12.0).astype(np.float32)
+    hd = y.DetectionHead(C, priors, (32.0,), (32.0,))
+    dheads = to_dev(heads, gpu)
+    thr, cap = 0.3, 2048
+    boxes, conf = hd.decode(dheads)
+    want_cc = (conf.cpu().numpy() >= np.float32(thr)).sum(axis=1).astype(np.int32)
+    per_image = want_cc.sum(axis=1)
+    assert per_image.max() > 16 * 4
+    staged = hd.nms(boxes, conf, thr, 0.5, 20, max_candidates=max(cap, int(per_image.max()) + 1), want_class_candidates=True)
+    assert not staged.overflowed()
+    want = staged.per_image()
+    for steps in (0, 1, 3, 16):
+        tuning(row_steps=steps)
+        got = y.DetectionHead(C, priors, (32.0,), (32.0,)).detect(dheads, thr, 0.5, 20, max_candidates=cap, want_class_candidates=True)
+        if per_image.max() > cap:
+            assert got.overflowed()                            # the capacity is the caller's; what was seen is reported
+            continue
+        assert not got.overflowed()
+        cases.same_detections(got.per_image(), want)
+        for a, b in zip(got.per_image(), want):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(got.class_candidates.cpu().numpy(), want_cc)
+
+
 def test_tile_kernel_with_a_fixed_number_of_workgroups(gpu, tuning):
     """yh_tuning.stream_resident: the workgroup-tile kernel launched as one workgroup per compute unit,
     each walking several runs of tiles (446 runs here), against one workgroup per run."""

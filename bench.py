@@ -460,6 +460,8 @@ def main():
             return reducer.global_mean(out)                  # the data-parallel scalar all-reduce
 
     def barrier():
+        if w['kind'] == 'loss':
+            reducer.flush()                                   # every step's collective is issued inside its region
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -64,24 +64,27 @@ _reducers = {}
 
 
 class PendingMean:
-    """The global mean loss of one step while its all-reduce may still be in flight: tensor() /
-    item() / float() wait for it (a stream-level wait under RCCL, no host synchronisation
-    before item()).  It lives in one of the reducer's `depth` persistent buffers: read it
-    before `depth` further steps have been reduced, later reads raise."""
+    """The global mean loss of one step while its all-reduce may still be pending or in flight:
+    tensor() / item() / float() issue it if need be and wait for it (a stream-level wait under RCCL,
+    no host synchronisation before item()).  It lives in one of the reducer's `depth` persistent
+    slots: read it before `depth // 2` further steps have been reduced, later reads may raise.
+    Every rank must read a step's value at the same point of the program, or none: a read may
+    issue the collective of the steps gathered so far."""
 
-    def __init__(self, reducer, slot, generation, work):
-        self._reducer, self._slot, self._generation, self._work = reducer, slot, generation, work
+    def __init__(self, reducer, slot, generation):
+        self._reducer, self._slot, self._generation = reducer, slot, generation
         self._done = False
 
     def tensor(self):
         r, k = self._reducer, self._slot
         if r._generation[k] != self._generation:
-            raise RuntimeError('this step\'s mean loss was not read within %d steps: its buffer has been reused' % len(r._ring))
+            raise RuntimeError('this step\'s mean loss was not read within %d steps: its buffer has been reused' % r.depth)
         if not self._done:
-            if self._work is not None:
-                self._work.wait()
-                self._work = None
-            r._out[k].copy_(r._ring[k][0] / r._ring[k][1])   # fp64 quotient, rounded to fp32 once
+            if not r._issued[k]:
+                r.flush()
+            if r._work[k] is not None:
+                r._work[k].wait()                            # shared by the slots of one collective: waiting again is free
+            r._out[k].copy_(r._buf[k, 0] / r._buf[k, 1])     # fp64 quotient, rounded to fp32 once
             self._done = True
         return r._out[k]
 
@@ -95,18 +98,49 @@ class LossReducer:
     """reduce_mean over the global batch (YOLOv3.py:311) for a step loop, without per-step
     allocations or host-to-device scalars: the loss kernel leaves the fp64 pair (sum of the
     per-image losses, image count) at the head of its workspace (DetectionHead.loss()
-    ['reduce_pair']); that pair is copied into one of `depth` persistent buffers and
-    all-reduced there asynchronously, so the next step's kernels may overwrite the workspace
-    while the collective is in flight.  With one rank nothing is exchanged and the kernel's
+    ['reduce_pair']); that pair is copied into the next slot of a persistent ring, so the next
+    step's kernels may overwrite the workspace, and the slots gathered so far are all-reduced in
+    place by ONE asynchronous collective when `batch` of them are waiting (default depth // 2),
+    when the ring wraps, when a step's value is read, or on flush().  A collective costs tens of
+    microseconds of host time whatever its size (one rank, RCCL: 66 us per step with one per step
+    against 27 us for the loss alone), a step's scalar is 16 bytes, and a step loop reads the value
+    for its log line at most; a loop that reads every step's value (train_one_epoch prints it)
+    gets one collective per step as before.  With one rank nothing is exchanged and the kernel's
     own fp32 mean is returned."""
 
-    def __init__(self, device, depth=4, always_reduce=False):
+    def __init__(self, device, depth=64, always_reduce=False, batch=None):
+        self.depth = int(depth)
         self.always_reduce = always_reduce                   # all-reduce even in a one-rank process group
-        self._ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(depth)]
-        self._out = [torch.zeros((), dtype=torch.float32, device=device) for _ in range(depth)]
-        self._work = [None] * depth
-        self._generation = [0] * depth
+        self._batch = max(1, min(self.depth, int(batch) if batch else self.depth // 2))
+        self._buf = torch.zeros((self.depth, 2), dtype=torch.float64, device=device)
+        self._out = torch.zeros((self.depth,), dtype=torch.float32, device=device)
+        self._work = [None] * self.depth
+        self._issued = [True] * self.depth
+        self._generation = [0] * self.depth
         self._i = 0
+        self._first, self._waiting = 0, 0                    # slots [first, first + waiting) hold pairs not yet reduced
+
+    def flush(self):
+        """Issues the collective of the slots gathered so far (every rank at the same point of the
+        program).  A benchmark calls it before it closes a timed region."""
+        n = self._waiting
+        if n == 0:
+            return
+        lo = self._first
+        part = self._buf[lo:lo + n]
+        # asynchronous under RCCL, where waiting is a stream-level dependency; the CPU-side backends (gloo:
+        # tests and rehearsals) complete the collective before returning
+        if dist.get_backend() == 'nccl':
+            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            host = part.cpu()                                # gloo reduces host memory; its device path is not relied upon
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            part.copy_(host)
+            work = None
+        for k in range(lo, lo + n):
+            self._work[k] = work
+            self._issued[k] = True
+        self._waiting = 0
 
     def global_mean(self, out_or_sum, local_batch=None, local_mean=None):
         """out_or_sum: the dict DetectionHead.loss() returned (preferred: carries reduce_pair), or
@@ -124,25 +158,23 @@ class LossReducer:
             if local_mean is not None:
                 return local_mean.reshape(())
             return local_sum.reshape(()) / float(local_batch)
-        k = self._i % len(self._ring)
+        k = self._i % self.depth
         self._i += 1
-        buf = self._ring[k]
         if self._work[k] is not None:
-            self._work[k].wait()                             # the buffer's previous collective, `depth` steps ago
+            self._work[k].wait()                             # the slot's previous collective, `depth` steps ago
+            self._work[k] = None
+        buf = self._buf[k]
         if pair is not None:
             buf.copy_(pair)
         else:
             buf[0:1].copy_(local_sum.reshape(1))
             buf[1].fill_(float(local_batch))
-        # asynchronous under RCCL, where waiting is a stream-level dependency; the CPU-side backends (gloo:
-        # tests and rehearsals) complete the collective before returning
-        if dist.get_backend() == 'nccl':
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            host = buf.cpu()                                 # gloo reduces host memory; its device path is not relied upon
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            buf.copy_(host)
-            work = None
-        self._work[k] = work
+        if self._waiting == 0:
+            self._first = k
+        self._waiting += 1
+        self._issued[k] = False
         self._generation[k] += 1
-        return PendingMean(self, k, self._generation[k], work)
+        pending = PendingMean(self, k, self._generation[k])
+        if self._waiting >= self._batch or k == self.depth - 1:   # a collective takes one contiguous run of slots
+            self.flush()
+        return pending

@@ -21,8 +21,9 @@ Workloads (BASELINE.json configs):
 
 Rank 0 prints ONE JSON line.
 
-`value` / `ms_per_step` come from the first timed region of exactly K steps (barrier and device
-synchronisation on both sides, maximum over ranks); `timing` adds the percentiles over that region
+`value` / `ms_per_step` come from the first timed region of exactly K steps: a barrier and a device
+synchronisation before it; after it every rank synchronises its device and stops its clock, then the ranks
+meet at a barrier again; the maximum over ranks counts.  `timing` adds the percentiles over that region
 and several more of the same length.
 
 `roofline` prices the dominant kernel, the pass over the head tensor:
@@ -459,10 +460,14 @@ def main():
                 out = reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
             return reducer.global_mean(out)                  # the data-parallel scalar all-reduce
 
-    def barrier():
+    def drain():
+        """Everything this rank has enqueued is complete when this returns."""
         if w['kind'] == 'loss':
             reducer.flush()                                   # every step's collective is issued inside its region
         torch.cuda.synchronize(dev)
+
+    def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -481,21 +486,27 @@ def main():
         barrier()
     for i in range(warmup):
         last = step(i)
+    # A timed region: all ranks leave a barrier with idle devices, every rank runs its K steps and stops its
+    # clock when its own device has finished them, the ranks meet again, and the slowest rank's time counts
+    # (the maximum is taken below).  The closing barrier's own latency, a collective of tens of microseconds
+    # under RCCL, is not part of any rank's K steps.
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         last = step(i)
     enqueue = time.perf_counter() - t0
-    barrier()
+    drain()
     elapsed = time.perf_counter() - t0
+    barrier()
     region_ms = [1e3 * elapsed / steps]
     for _ in range(max(0, args.regions)):                   # more regions of the same length, for the spread
         barrier()
         t1 = time.perf_counter()
         for i in range(steps):
             last = step(i)
-        barrier()
+        drain()
         region_ms.append(1e3 * (time.perf_counter() - t1) / steps)
+        barrier()
     gc.enable()
 
     kern_runs = None

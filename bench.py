@@ -327,6 +327,9 @@ def main():
                          '1 = one stream, launches back to back; default 3')
     ap.add_argument('--detect-kernel', type=int, default=0, choices=(0, 1, 2),
                     help='yh_set_tuning.detect_kernel: 0/1 = objectness-first rows kernel, 2 = streaming kernel')
+    ap.add_argument('--input-sets', type=int, default=0,
+                    help='distinct input sets the steps rotate through (default: sized by the bytes a step touches, so '
+                         'that a line is re-read only after 3x the Infinity Cache of other lines)')
     ap.add_argument('--row-steps', type=int, default=0,
                     help='yh_set_tuning.row_steps: steps of 64 rows per work unit of the rows kernel (0 = planned from the batch)')
     ap.add_argument('--stream-resident', type=int, default=0,
@@ -394,7 +397,7 @@ def main():
         kname, kdesc = 'k_loss_main', 'k_loss_main (ignore-mask IoU loop + assignment + loss sums; reads the objectness column and the assigned rows)'
         touched = rows_per_launch * 128.0 * (3.0 if w.get('backward') else 1.0)
     if decoded is None:
-        rotate = rotation_for(touched, cap=24 if B * bytes_img < (1 << 30) else 4)
+        rotate = args.input_sets or rotation_for(touched, cap=24 if B * bytes_img < (1 << 30) else 4)
         sets = [probe if (i == 0 and probe is not None) else
                 y.synth.torch_heads(dev, 1000 * rank + i, B, grids, P, C, **w.get('dist', {})) for i in range(rotate)]
     else:

@@ -6,8 +6,11 @@
 A step is one pass of the path over one batch of synthetic head tensors that
 are resident in HBM before the timed region starts.  For N > 1 the driver
 launches one rank per GPU (torch.distributed.run); images are sharded by rank
-(weak scaling: every rank owns a full per-GPU batch), the detect workloads need
-no collective and the loss workload all-reduces one scalar over RCCL.
+(weak scaling by default: every rank owns a full per-GPU batch; with
+--global-batch G strong scaling: rank r owns the images parallel.shard_range(G,
+r, N) of a fixed global batch), the detect workloads need no collective and the
+loss workloads all-reduce one scalar pair over RCCL, one collective per step
+(--steps-per-collective n gathers n steps per collective; reported in config).
 
 Workloads (BASELINE.json configs):
   detect416  config 2  YOLOv3-416 COCO-80, batch 64 / GPU, decode + score filter + per-class NMS   [default]
@@ -318,6 +321,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='detect416', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='images per GPU (default: the workload\'s)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling: a fixed global batch of this many images, rank r takes the contiguous range '
+                         'parallel.shard_range(G, r, world) (BASELINE config 4: 512 -> 256/128/64 per GPU at 2/4/8 GPUs; '
+                         'config 3: 256 -> 32 per GPU at 8); value = G * steps / time of the slowest rank')
+    ap.add_argument('--steps-per-collective', type=int, default=1,
+                    help='loss workloads: steps whose scalar pairs share one all-reduce (default 1: a collective per '
+                         'step, what a loop that reads every step\'s loss pays)')
     ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
                     help='detect workloads: 2 = software pipeline (a step streams batch i and selects batch '
                          'i-1 in one launch), 1 = every batch runs to completion before the next')
@@ -358,6 +368,13 @@ def main():
 
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w['batch']
+    if args.global_batch:
+        if args.batch:
+            raise SystemExit('--batch and --global-batch exclude each other')
+        lo, hi = y.parallel.shard_range(args.global_batch, rank, world)
+        B = hi - lo
+        if B < 1:
+            raise SystemExit('--global-batch %d leaves rank %d of %d without an image' % (args.global_batch, rank, world))
     grids, priors, box_mult, gt_rate = build_head(w)
     P, C = len(priors[0]), w['C']
     K = C + 5
@@ -449,7 +466,9 @@ def main():
     else:
         gts = [torch.from_numpy(y.synth.make_ground_truth(77 + 10 * rank + i, B, w['G'], w['pad'], w['size'], C)).to(dev)
                for i in range(rotate)]
-        reducer = y.parallel.LossReducer(dev, always_reduce=args.force_allreduce)   # persistent buffers: no allocation per step
+        # persistent buffers: no allocation per step; one collective per --steps-per-collective steps
+        reducer = y.parallel.LossReducer(dev, always_reduce=args.force_allreduce, batch=max(1, args.steps_per_collective))
+        extra['steps_per_collective'] = reducer._batch if (world > 1 or args.force_allreduce) else None
         if args.force_allreduce:
             extra['allreduce'] = 'forced: %d-rank %s process group' % (world, dist.get_backend())
         reuse = {}                                           # the loss outputs are written in place step after step
@@ -458,7 +477,7 @@ def main():
             if w.get('backward'):
                 # forward + backward in one library call: d(.5 * mean loss) / d(head) for every head
                 out, _grads = hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True,
-                                               grad_scale=0.5 / y.parallel.global_batch(B))
+                                               grad_scale=0.5 / (args.global_batch or y.parallel.global_batch(B)))
             else:
                 out = reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
             return reducer.global_mean(out)                  # the data-parallel scalar all-reduce
@@ -466,7 +485,7 @@ def main():
     def drain():
         """Everything this rank has enqueued is complete when this returns."""
         if w['kind'] == 'loss':
-            reducer.flush()                                   # every step's collective is issued inside its region
+            reducer.flush()                                   # steps still gathered (--steps-per-collective > 1) go out inside the region
         torch.cuda.synchronize(dev)
 
     def barrier():
@@ -587,20 +606,22 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        value = world * B * steps / elapsed
+        images_per_step = args.global_batch or world * B
+        value = images_per_step * steps / elapsed
         kern_ms = float(np.median(kern_runs))
-        config = dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=B * world,
+        config = dict(workload=w['name'], workload_key=args.workload, batch_per_gpu=B, global_batch=images_per_step,
                       boxes_per_image=N, num_classes=C, bytes_per_image=bytes_img,
                       parallelism='images sharded across %d GPU(s), no data-path collective' % world
                       if w['kind'] in ('detect', 'nms') else
-                      'images sharded across %d GPU(s), one scalar all-reduce (RCCL) per step' % world,
+                      'images sharded across %d GPU(s), one all-reduce (RCCL) of the fp64 pair (loss sum, image count) per '
+                      '%d step(s)' % (world, max(1, args.steps_per_collective)),
                       input_rotation=rotation_note, **extra)
         if surv0 is not None:
             config['row_survival'] = round(row_survival(sets, C, w['thr']), 5)
         res = {
             'metric': 'images/sec (decode+IoU+NMS) YOLOv3-416 COCO-80 at 1/2/4/8 GPU; % HBM peak',
             'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
-            'ms_per_step': round(1e3 * elapsed / steps, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * elapsed / steps, 5), 'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': config,
             'timing': dict(regions_ms_per_step=[round(r, 5) for r in region_ms], **percentiles(region_ms),
                            note='region 0 is the one value / ms_per_step report; every region is %d steps between '
@@ -647,6 +668,15 @@ def main():
             del sets
             torch.cuda.empty_cache()
             res['survival_sweep'] = survival_sweep(w, grids, priors, box_mult, gt_rate, dev, B, rows_per_launch, K)
+            worst = max(res['survival_sweep'], key=lambda r: r['kernel_us'])
+            res['worst_case'] = dict(
+                row_survival=worst['row_survival'], kernel_us=worst['kernel_us'],
+                images_per_sec=round(B / (worst['kernel_us'] * 1e-6), 1),
+                algorithmic_frac=round(algo / (worst['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                note='the slowest point of survival_sweep (every row passes the objectness prefilter, so the whole head is '
+                     'read): launches back to back on one stream; images_per_sec = batch / kernel time, algorithmic_frac = '
+                     'N*(C+5)*4 bytes per image over that time against the 8 TB/s peak; `value` above holds at row_survival '
+                     '%.4f' % config.get('row_survival', 0.0))
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(w, grids, priors, box_mult, gt_rate)
         print(json.dumps(res), flush=True)

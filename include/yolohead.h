@@ -95,7 +95,11 @@ const char *yh_last_error(void);
  *                   tiles the pass is cut into;
  *   stream_resident workgroup-tile variant: workgroups launched per compute unit,
  *                   each walking the cuts in turn (default: one workgroup per
- *                   cut, as many launched as there are cuts). */
+ *                   cut, as many launched as there are cuts);
+ *   rows_dense_min  rows kernel: a step of 64 rows of which at least this many
+ *                   pass the objectness prefilter is read whole, as one
+ *                   contiguous span, instead of row by row (default: from the
+ *                   row width, 30 at 85 floats per row; 65 = never). */
 typedef struct yh_tuning {
     int32_t detect_kernel;
     int32_t row_steps;
@@ -104,6 +108,7 @@ typedef struct yh_tuning {
     int32_t stream_units;
     int32_t stream_blocks;
     int32_t stream_resident;
+    int32_t rows_dense_min;
 } yh_tuning;
 int yh_set_tuning(const yh_tuning *tuning);   /* NULL restores the defaults */
 int yh_get_tuning(yh_tuning *tuning);

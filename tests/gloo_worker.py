@@ -47,5 +47,22 @@ for step, p in list(enumerate(pending))[1:]:
     assert isinstance(p, y.parallel.PendingMean)
     np.testing.assert_allclose(p.item(), want64 * (step + 1), rtol=1e-6)
     assert p.tensor().dtype == torch.float32 and p.tensor().dim() == 0
+# gathered steps: one collective per three steps, issued by the third call or by flush() on every rank; a read
+# never issues one (a rank reading alone would otherwise enter the all-reduce alone)
+red3 = y.parallel.LossReducer(torch.device('cpu'), depth=8, batch=3)
+pend3 = []
+for step in range(4):
+    sum64 = float(np.sum(per_local.astype(np.float64))) * (step + 1)
+    out = dict(sum=torch.tensor([sum64], dtype=torch.float32), mean=None, per_image=torch.zeros(b1 - b0),
+               reduce_pair=torch.tensor([sum64, b1 - b0], dtype=torch.float64))
+    pend3.append(red3.global_mean(out))
+np.testing.assert_allclose(pend3[2].item(), want64 * 3, rtol=1e-6)      # steps 0..2 went out with the third call
+try:
+    pend3[3].item()
+    raise AssertionError('reading a step whose collective has not been issued must raise')
+except RuntimeError:
+    pass
+red3.flush()
+np.testing.assert_allclose(pend3[3].item(), want64 * 4, rtol=1e-6)
 print('GLOO_OK rank %d mean %.6f' % (rank, float(mean)))
 dist.destroy_process_group()

@@ -69,6 +69,33 @@ def test_host_side_validation_needs_no_gpu():
     assert call(0x6000, _abi.pointer_array([0])) == _abi.YH_ERR_INVALID_ARG
 
 
+def test_rows_wider_than_a_tile_are_refused_not_divided_by():
+    """The workgroup-tile streaming kernel holds whole rows in a 4096-float LDS tile; the ABI admits
+    4096 classes.  Shapes that select that kernel with wider rows must come back as YH_ERR_LIMIT from
+    the host-side plan (the plan once divided by the tile's row count, which is zero there)."""
+    lib = _abi.load()
+    nbytes = ctypes.c_size_t(0)
+    wide = y.make_config([(2, 2)], [[[1.0, 1.0]]], [32], [32], 4096)
+    # dense candidate sets (capacity above the single-launch select stage) take the tile kernel
+    assert lib.yh_detect_workspace_bytes(ctypes.byref(wide), 2, 5000, 10, ctypes.byref(nbytes)) == _abi.YH_ERR_LIMIT
+    assert b'tile' in lib.yh_last_error()
+    # ... the objectness-first kernel takes any row
+    _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(wide), 2, 512, 10, ctypes.byref(nbytes)))
+    edge = y.make_config([(2, 2)], [[[1.0, 1.0]]], [32], [32], 4088)         # 4093 floats per row: the widest that fits
+    _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(edge), 2, 5000, 10, ctypes.byref(nbytes)))
+    edge.num_classes = 4089
+    assert lib.yh_detect_workspace_bytes(ctypes.byref(edge), 2, 5000, 10, ctypes.byref(nbytes)) == _abi.YH_ERR_LIMIT
+    # yh_nms streams rows of C confidences through the same kernel
+    for C, ok in ((4093, True), (4094, False), (4096, False)):
+        rc = lib.yh_nms_workspace_bytes(2, 100, C, 1000, 10, ctypes.byref(nbytes))
+        assert (rc == _abi.YH_OK) == ok and (ok or rc == _abi.YH_ERR_LIMIT)
+        if not ok:
+            # fake, never dereferenced addresses: the size checks come before anything touches a device
+            rc = lib.yh_nms(2, 100, C, 0x1000, 0x2000, 0.5, 0.5, 10, 1000, 0x3000, 1 << 30, 0x4000, 0x5000, 0x6000, 0x7000,
+                            0x8000, None, 0x9000, None)
+            assert rc == _abi.YH_ERR_LIMIT and b'confidences' in lib.yh_last_error()
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -7,31 +7,13 @@ import torch
 
 import yolo_tf_amd as y
 from tests import cases
-from tests.test_gpu_parity import to_dev, assert_close, _fragile, RTOL
+from tests.test_gpu_parity import to_dev, assert_close, end_to_end_against_oracle, RTOL
 
 pytestmark = pytest.mark.gpu
 
 
 def _end_to_end(case, heads, thr, iou, mb, gpu, c_oracle, **kw):
-    B = heads[0].shape[0]
-    want = c_oracle.detect(case.oracle_cfg(c_oracle), heads, thr, iou, mb)
-    wbox, wconf = c_oracle.decode(case.oracle_cfg(c_oracle), heads)
-    got = case.head_obj().detect(to_dev(heads, gpu), thr, iou, mb, **kw).per_image()
-    checked = excused = 0
-    for b in range(B):
-        for c in range(case.C):
-            gm, wm = got[b][2] == c, want[b][2] == c
-            if not wm.any() and not gm.any():
-                continue
-            checked += 1
-            if np.array_equal(got[b][3][gm], want[b][3][wm]):
-                assert_close(got[b][0][gm], want[b][0][wm], what='scores')
-                assert_close(got[b][1][gm], want[b][1][wm], rtol=RTOL, atol=RTOL * case.size, what='bbox')
-            else:
-                assert _fragile(wbox[b], wconf[b, :, c], thr, iou), \
-                    'image %d class %d: kept rows differ away from any decision boundary' % (b, c)
-                excused += 1
-    assert checked > 0 and excused <= max(1, checked // 50), '%d of %d classes excused' % (excused, checked)
+    return end_to_end_against_oracle(case, heads, thr, iou, mb, gpu, c_oracle, **kw)
 
 
 def _nms_stage_bit_exact(case, dheads, thr, iou, mb, c_oracle, **kw):

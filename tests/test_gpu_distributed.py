@@ -58,22 +58,29 @@ print('RCCL_OK')
     assert r.returncode == 0, r.stdout + r.stderr
     line = _last_json(r.stdout)
     assert line['config']['allreduce'] == 'forced: 1-rank nccl process group'
+    assert line['config']['steps_per_collective'] == 1
     assert line['value'] > 0 and line['config']['mean_loss_last_step'] > 0
 
 
-@pytest.mark.parametrize('workload', ['detect416', 'loss416'])
+@pytest.mark.parametrize('workload', ['detect416', 'loss416', 'detect608-strong'])
 def test_bench_under_two_gloo_ranks(gpu, workload):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run), with the gloo backend
     because both ranks share this box's one GPU: sharding, barrier, max-over-ranks timing, the
     scalar all-reduce of the loss workload, one JSON line from rank 0."""
     env = dict(os.environ, YH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = {'detect416': '29747', 'loss416': '29757'}[workload]      # a port of its own: the last run's may still be closing
+    port = {'detect416': '29747', 'loss416': '29757', 'detect608-strong': '29767'}[workload]   # a port of its own: the last run's may still be closing
+    strong = workload.endswith('-strong')                   # a fixed global batch of 16 images split over the ranks
+    workload = workload.split('-')[0]
+    size = ['--global-batch', '16'] if strong else ['--batch', '8']
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                         '--master-addr', '127.0.0.1', '--master-port', port, os.path.join(ROOT, 'bench.py'),
                         '--gpus', '2', '--steps', '20', '--warmup', '2', '--regions', '1', '--workload', workload,
-                        '--batch', '8', '--no-cpu-baseline'],
+                        *size, '--no-cpu-baseline'],
                        capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = _last_json(r.stdout)
-    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16 and line['scaling'] == 'weak'
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16 and line['config']['batch_per_gpu'] == 8
+    assert line['scaling'] == ('strong' if strong else 'weak')
+    if workload == 'loss416':
+        assert line['config']['steps_per_collective'] == 1
     assert line['value'] > 0 and sum(1 for l in r.stdout.splitlines() if l.startswith('{')) == 1

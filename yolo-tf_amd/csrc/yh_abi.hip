@@ -189,8 +189,10 @@ constexpr uint64_t kRowsResidentGroups = 768;
 
 // Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
 // relaxed atomics; 0 = the built-in default.
-std::atomic<int32_t> g_tuning[7];
-enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks, kTuneStreamResident };
+constexpr int kTuneFields = 8;
+std::atomic<int32_t> g_tuning[kTuneFields];
+enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks, kTuneStreamResident,
+       kTuneRowsDenseMin };
 
 long knob(int which, long fallback)
 {
@@ -251,6 +253,19 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
             p.sc[s].unit_base = upi;
             upi += (uint32_t)chunks;
         }
+        // A step is read whole (one contiguous span of 64 rows) instead of row by row once so many of its rows
+        // survive that the gathers would fetch about as many new cache lines as the span holds beyond the
+        // objectness lines already fetched: lines of the span 64 * 4K / 128 = 2K, of which min(64, 2K) came with
+        // the objectness column; a surviving row brings 4K / 128 new lines.  Streaming loads move a line
+        // more cheaply than gathers do, hence the factor 3/4.  (K = 85: 30 of 64 rows.)
+        {
+            const double span_lines = 2.0 * p.K, col_lines = std::min(64.0, span_lines);
+            const double per_row = std::max(0.25, p.K / 32.0);
+            long dm = std::lround(0.75 * (span_lines - col_lines) / per_row);
+            dm = std::min<long>(64, std::max<long>(4, dm));
+            p.dense_min = (int32_t)knob(kTuneRowsDenseMin, dm);
+            p.dense_col_step = 256 % p.K;
+        }
         p.units = (upi + waves - 1) / waves;                     // workgroups per image
         p.upi = (int32_t)(p.units * waves);
         return p.units * (uint32_t)B;
@@ -284,6 +299,10 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
         return units;                                            // one wavefront per workgroup
     }
     p.tile_rows = (yh::kTileFloats - 3) / p.K;
+    if (p.tile_rows < 1) {                                       // a row wider than a tile: no plan, check_plan() refuses the call
+        p.cuts = p.grid_blocks = 0;
+        return 0;
+    }
     uint64_t total_tiles = 0;
     for (int s = 0; s < p.S; ++s)
         total_tiles += ((uint64_t)p.sc[s].rows_img + p.tile_rows - 1) / p.tile_rows * (uint64_t)B;
@@ -308,6 +327,18 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
     const uint64_t resident = (uint64_t)knob(kTuneStreamResident, 0) * (uint64_t)compute_units();
     if (resident > 0 && resident < blocks) p.grid_blocks = (uint32_t)resident;
     return blocks;
+}
+
+// The workgroup-tile kernel holds whole rows in its LDS tile (three floats of it absorb the tile's 16-byte
+// phase): wider rows have no plan there.  The objectness-first and the full-decode kernels take any row.
+int check_plan(const yh::StreamParams &p, yh::StreamMode mode)
+{
+    if (mode != yh::kModeFull && !p.wave_ni && !p.row_gather && p.tile_rows < 1)
+        return fail(YH_ERR_LIMIT, "rows of %d floats do not fit the %d-float tile of the streaming kernel this call selects "
+                    "(%s): at most %d classes there", p.K, yh::kTileFloats,
+                    mode == yh::kModeConf ? "yh_nms" : "max_candidates above 2048 or detect_kernel = 2",
+                    yh::kTileFloats - 3 - (mode == yh::kModeConf ? 0 : 5));
+    return YH_OK;
 }
 
 void fill_stream_from_config(yh::StreamParams &p, const yh_head_config *cfg, const float *const *heads, int B)
@@ -369,12 +400,12 @@ int yh_version(void) { return 200; }
 
 int yh_set_tuning(const yh_tuning *t)
 {
-    const int32_t v[7] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
-                          t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0,
-                          t ? t->stream_resident : 0};
-    for (int i = 0; i < 7; ++i)
+    const int32_t v[kTuneFields] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
+                                    t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0,
+                                    t ? t->stream_resident : 0, t ? t->rows_dense_min : 0};
+    for (int i = 0; i < kTuneFields; ++i)
         if (v[i] < 0) return fail(YH_ERR_INVALID_ARG, "tuning field %d is negative", i);
-    for (int i = 0; i < 7; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
+    for (int i = 0; i < kTuneFields; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
     return YH_OK;
 }
 
@@ -388,6 +419,7 @@ int yh_get_tuning(yh_tuning *t)
     t->stream_units = g_tuning[kTuneStreamUnits].load(std::memory_order_relaxed);
     t->stream_blocks = g_tuning[kTuneStreamBlocks].load(std::memory_order_relaxed);
     t->stream_resident = g_tuning[kTuneStreamResident].load(std::memory_order_relaxed);
+    t->rows_dense_min = g_tuning[kTuneRowsDenseMin].load(std::memory_order_relaxed);
     return YH_OK;
 }
 
@@ -459,7 +491,11 @@ int yh_detect_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t 
         return fail(YH_ERR_INVALID_ARG, "bad batch / max_candidates / nms_max_boxes");
     yh::StreamParams p;
     fill_stream_from_config(p, cfg, nullptr, batch);
-    if (batch > 0) plan_stream(p, batch, yh::kModeDetect, max_candidates);
+    if (batch > 0) {
+        plan_stream(p, batch, yh::kModeDetect, max_candidates);
+        const int prc = check_plan(p, yh::kModeDetect);
+        if (prc != YH_OK) return prc;
+    }
     *bytes = carve_for_plan(nullptr, p, batch, max_candidates, nms_max_boxes).bytes;
     return YH_OK;
 }
@@ -471,6 +507,9 @@ int yh_nms_workspace_bytes(int32_t batch, int64_t boxes_per_img, int32_t num_cla
     if (batch < 0 || boxes_per_img < 1 || num_classes < 1 || max_candidates < 1 || nms_max_boxes < 1 ||
         nms_max_boxes > YH_MAX_NMS_BOXES)
         return fail(YH_ERR_INVALID_ARG, "bad size argument");
+    if (num_classes > YH_MAX_CLASSES || num_classes > yh::kTileFloats - 3)
+        return fail(YH_ERR_LIMIT, "num_classes %d: yh_nms streams rows of at most %d confidences", num_classes,
+                    std::min<int>(YH_MAX_CLASSES, yh::kTileFloats - 3));
     *bytes = carve_detect(nullptr, batch, boxes_per_img, num_classes, max_candidates, nms_max_boxes, false, false, 0).bytes;
     return YH_OK;
 }
@@ -543,6 +582,7 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
     yh::StreamParams &p = d.p;
     fill_stream_from_config(p, cfg, want_stream ? heads : nullptr, batch);
     d.blocks = plan_stream(p, batch, yh::kModeDetect, max_candidates);
+    if ((rc = check_plan(p, yh::kModeDetect)) != YH_OK) return rc;
     const DetectWs w = carve_for_plan(workspace, p, batch, max_candidates, nms_max_boxes);
     if (workspace_bytes < w.bytes)
         return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
@@ -756,6 +796,8 @@ static int nms_impl(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
         return fail(YH_ERR_LIMIT, "boxes_per_image %lld outside [1, %d]", (long long)boxes_per_img, YH_MAX_BOXES_PER_IMAGE);
     if ((boxes_per_img * num_classes + num_classes) * (int64_t)num_classes >= (int64_t)1 << 32)
         return fail(YH_ERR_LIMIT, "boxes_per_image * num_classes^2 exceeds 2^32");
+    if (num_classes > yh::kTileFloats - 3)
+        return fail(YH_ERR_LIMIT, "num_classes %d: yh_nms streams rows of at most %d confidences", num_classes, yh::kTileFloats - 3);
     if (batch == 0) return YH_OK;
     if (!boxes || !conf) return fail(YH_ERR_INVALID_ARG, "boxes or conf is null");
     if ((reinterpret_cast<uintptr_t>(boxes) & 15u) || (reinterpret_cast<uintptr_t>(conf) & 15u) ||

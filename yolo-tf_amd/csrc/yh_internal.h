@@ -38,11 +38,21 @@ __device__ inline float key_score(unsigned long long k)
 // ---- arithmetic shared by every kernel (fp32, no contraction) -----------
 // Both the decode (YOLOv3.py:338-345: sigmoid of the class, objectness and centre logits, exp of the
 // size logits) and the loss (sigmoid cross-entropy and its derivative) use the hardware's exp2, log2
-// and reciprocal, one ulp each: exp(x) = exp2(x * log2(e)) carries the rounding of the product into
-// the exponent, a relative error below 2^-23 * (2 + 1.45 |x|), i.e. 2e-6 at |x| = 10 and 8e-6 at
-// the largest finite results, inside the 1e-5 the path is held to.  Every decode kernel uses these
-// two functions, so the staged and the fused paths agree bit for bit.
-__device__ __forceinline__ float decode_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// and reciprocal, one ulp each.  exp(x) = exp2(x * log2(e)): a plain product would carry its rounding
+// (and that of the constant) into the exponent, a relative error that grows as 8e-8 |x| and passes
+// 5e-6 at the largest finite results.  The product is therefore taken in two parts: p = RN(x * hi),
+// d = the exact remainder x * hi - p plus x * lo (hi + lo = log2(e) to 2^-50), and
+// exp2(p + d) = exp2(p) * (1 + d ln 2) with |d| < 2^-17: three ulp whatever |x| is.  An overflowing
+// exp2(p) stays +inf (the factor is within 1e-5 of one) and an underflowing one stays 0.
+// Every decode kernel uses these two functions, so the staged and the fused paths agree bit for bit.
+__device__ __forceinline__ float decode_exp(float x)
+{
+    const float hi = 1.44269502162933349609375f;        // RN(log2 e)
+    const float lo = 1.92596299112661747e-8f;             // log2 e - hi
+    const float p = x * hi;
+    const float d = __builtin_fmaf(x, lo, __builtin_fmaf(x, hi, -p));
+    return __builtin_amdgcn_exp2f(p) * __builtin_fmaf(d, 0.693147180559945309417f, 1.0f);
+}
 __device__ __forceinline__ float decode_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + decode_exp(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return decode_sigmoid(x); }
 // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|)).  With t = exp(-|x|)
@@ -97,6 +107,8 @@ struct StreamParams {
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
     int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
     uint32_t units;         // objectness-first variant: workgroups per image (kRowsThreads / 64 units each)
+    int32_t dense_min;      // objectness-first variant: a step with at least this many surviving rows is read whole
+    int32_t dense_col_step; // ... (floats a wavefront covers per 16-byte load: 256) mod K
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     uint32_t cuts;          // workgroup-tile variant: runs of tiles the pass is cut into (a workgroup's worth each)
     uint32_t grid_blocks;   // workgroup-tile variant: workgroups launched; fewer than `cuts`: each walks cuts

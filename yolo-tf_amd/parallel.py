@@ -64,12 +64,14 @@ _reducers = {}
 
 
 class PendingMean:
-    """The global mean loss of one step while its all-reduce may still be pending or in flight:
-    tensor() / item() / float() issue it if need be and wait for it (a stream-level wait under RCCL,
-    no host synchronisation before item()).  It lives in one of the reducer's `depth` persistent
-    slots: read it before `depth // 2` further steps have been reduced, later reads may raise.
-    Every rank must read a step's value at the same point of the program, or none: a read may
-    issue the collective of the steps gathered so far."""
+    """The global mean loss of one step while its all-reduce may still be in flight: tensor() /
+    item() / float() wait for it (a stream-level wait under RCCL, no host synchronisation before
+    item()).  A read never issues a collective (a rank that logs while the others do not would
+    otherwise enter an all-reduce alone): with the reducer's default of one collective per step the
+    value's collective has been issued before this object exists; with `batch` > 1 every rank
+    calls `reducer.flush()` at the same point of its program before anybody reads, and a read of
+    a step that is still waiting raises.  The value lives in one of the reducer's `depth`
+    persistent slots: read it before `depth` further steps have been reduced, later reads raise."""
 
     def __init__(self, reducer, slot, generation):
         self._reducer, self._slot, self._generation = reducer, slot, generation
@@ -81,7 +83,8 @@ class PendingMean:
             raise RuntimeError('this step\'s mean loss was not read within %d steps: its buffer has been reused' % r.depth)
         if not self._done:
             if not r._issued[k]:
-                r.flush()
+                raise RuntimeError('this step\'s pair has not been all-reduced yet: LossReducer(batch=%d) gathers steps, '
+                                   'call flush() on every rank before any rank reads' % r._batch)
             if r._work[k] is not None:
                 r._work[k].wait()                            # shared by the slots of one collective: waiting again is free
             r._out[k].copy_(r._buf[k, 0] / r._buf[k, 1])     # fp64 quotient, rounded to fp32 once
@@ -100,18 +103,19 @@ class LossReducer:
     per-image losses, image count) at the head of its workspace (DetectionHead.loss()
     ['reduce_pair']); that pair is copied into the next slot of a persistent ring, so the next
     step's kernels may overwrite the workspace, and the slots gathered so far are all-reduced in
-    place by ONE asynchronous collective when `batch` of them are waiting (default depth // 2),
-    when the ring wraps, when a step's value is read, or on flush().  A collective costs tens of
-    microseconds of host time whatever its size (one rank, RCCL: 66 us per step with one per step
-    against 27 us for the loss alone), a step's scalar is 16 bytes, and a step loop reads the value
-    for its log line at most; a loop that reads every step's value (train_one_epoch prints it)
-    gets one collective per step as before.  With one rank nothing is exchanged and the kernel's
-    own fp32 mean is returned."""
+    place by ONE asynchronous collective when `batch` of them are waiting, when the ring wraps, or
+    on flush().  `batch` defaults to 1: one collective per step, issued by the call itself on
+    every rank, so a value can be read by any subset of ranks at any time (train_one_epoch prints
+    every step's).  A collective costs tens of microseconds of host time whatever its size (one
+    rank, RCCL: 66 us per step with one per step against 27 us for the loss alone) and a step's
+    scalar is 16 bytes, so a loop that reads the loss rarely may pass batch=n: one collective per n
+    steps, and the loop calls flush() on every rank before it reads.  With one rank nothing is
+    exchanged and the kernel's own fp32 mean is returned."""
 
-    def __init__(self, device, depth=64, always_reduce=False, batch=None):
+    def __init__(self, device, depth=64, always_reduce=False, batch=1):
         self.depth = int(depth)
         self.always_reduce = always_reduce                   # all-reduce even in a one-rank process group
-        self._batch = max(1, min(self.depth, int(batch) if batch else self.depth // 2))
+        self._batch = max(1, min(self.depth, int(batch) if batch else 1))
         self._buf = torch.zeros((self.depth, 2), dtype=torch.float64, device=device)
         self._out = torch.zeros((self.depth,), dtype=torch.float32, device=device)
         self._work = [None] * self.depth
@@ -121,8 +125,8 @@ class LossReducer:
         self._first, self._waiting = 0, 0                    # slots [first, first + waiting) hold pairs not yet reduced
 
     def flush(self):
-        """Issues the collective of the slots gathered so far (every rank at the same point of the
-        program).  A benchmark calls it before it closes a timed region."""
+        """Issues the collective of the slots gathered so far; every rank calls it at the same point
+        of its program.  Nothing to do with the default of one collective per step."""
         n = self._waiting
         if n == 0:
             return

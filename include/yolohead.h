@@ -96,10 +96,12 @@ const char *yh_last_error(void);
  *   stream_resident workgroup-tile variant: workgroups launched per compute unit,
  *                   each walking the cuts in turn (default: one workgroup per
  *                   cut, as many launched as there are cuts);
- *   rows_dense_min  rows kernel: a step of 64 rows of which at least this many
- *                   pass the objectness prefilter is read whole, as one
- *                   contiguous span, instead of row by row (default: from the
- *                   row width, 30 at 85 floats per row; 65 = never). */
+ *   rows_dense_min  rows kernel: a work unit of whose sixteen sampled rows at
+ *                   least this many in 64 pass the objectness prefilter is read
+ *                   whole, as contiguous spans, instead of row by row (default:
+ *                   from the row width, 40 at 85 floats per row; 65 = never);
+ *   rows_probe      rows kernel: 1 (default) units sample their rows as above;
+ *                   2: no unit is read whole. */
 typedef struct yh_tuning {
     int32_t detect_kernel;
     int32_t row_steps;
@@ -109,6 +111,7 @@ typedef struct yh_tuning {
     int32_t stream_blocks;
     int32_t stream_resident;
     int32_t rows_dense_min;
+    int32_t rows_probe;
 } yh_tuning;
 int yh_set_tuning(const yh_tuning *tuning);   /* NULL restores the defaults */
 int yh_get_tuning(yh_tuning *tuning);

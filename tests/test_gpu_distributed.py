@@ -67,7 +67,8 @@ def test_bench_under_two_gloo_ranks(gpu, workload):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run), with the gloo backend
     because both ranks share this box's one GPU: sharding, barrier, max-over-ranks timing, the
     scalar all-reduce of the loss workload, one JSON line from rank 0."""
-    env = dict(os.environ, YH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # the watchdog makes a rank that hangs dump its threads' stacks and exit, so that the failure names its place
+    env = dict(os.environ, YH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', YH_BENCH_WATCHDOG='120')
     port = {'detect416': '29747', 'loss416': '29757', 'detect608-strong': '29767'}[workload]   # a port of its own: the last run's may still be closing
     strong = workload.endswith('-strong')                   # a fixed global batch of 16 images split over the ranks
     workload = workload.split('-')[0]
@@ -76,7 +77,7 @@ def test_bench_under_two_gloo_ranks(gpu, workload):
                         '--master-addr', '127.0.0.1', '--master-port', port, os.path.join(ROOT, 'bench.py'),
                         '--gpus', '2', '--steps', '20', '--warmup', '2', '--regions', '1', '--workload', workload,
                         *size, '--no-cpu-baseline'],
-                       capture_output=True, text=True, timeout=400, env=env)
+                       capture_output=True, text=True, timeout=170, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = _last_json(r.stdout)
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16 and line['config']['batch_per_gpu'] == 8

@@ -26,7 +26,7 @@ def test_rows_kernel_random_sweep(gpu, tuning):
     for it in range(60):
         S, P, C, grids, priors, mult = _geometry(rng, [1, 7, 20, 80, 96, 97, 113, 200], 60)
         B = int(rng.integers(1, 5))
-        dist = dict(obj_mean=float(rng.choice([-6., -4., -3., -1.])), obj_std=float(rng.choice([1., 2., 3.])),
+        dist = dict(obj_mean=float(rng.choice([-6., -4., -3., -1., 0., 2., 6.])), obj_std=float(rng.choice([1., 2., 3.])),
                     hot_mean=float(rng.choice([-1., 1., 3.])), cold_mean=float(rng.choice([-8., -5., -3.])),
                     cold_std=float(rng.choice([0.5, 1.5])))
         thr, mb = float(rng.choice([0.1, 0.3, 0.5, 0.8])), int(rng.choice([1, 5, 20, 100]))
@@ -38,8 +38,12 @@ def test_rows_kernel_random_sweep(gpu, tuning):
         most = int(cc.sum(axis=1).max())
         staged = hd.nms(boxes, conf, thr, 0.5, mb, max_candidates=max(2048, most + 1), want_class_candidates=True)
         assert not staged.overflowed()
-        for steps in (0, int(rng.integers(1, 17))):
-            tuning(row_steps=steps)
+        # the plan's own steps per unit and a random number of them; steps read whole from the default number of
+        # surviving rows, from a single one (nearly every step then, entered through the objectness column, through
+        # the probe of the unit's first step, or blind behind another whole step) and never
+        for steps, dense_min, probe in ((0, 0, 0), (int(rng.integers(1, 17)), int(rng.choice([1, 8, 30])), int(rng.choice([1, 2]))),
+                                        (int(rng.integers(1, 17)), 65, 0), (0, 1, 1)):
+            tuning(row_steps=steps, rows_dense_min=dense_min, rows_probe=probe)
             got = y.DetectionHead(C, priors, mult, mult).detect(dheads, thr, 0.5, mb, max_candidates=2048,
                                                                 want_class_candidates=True)
             if most > 2048:
@@ -51,7 +55,7 @@ def test_rows_kernel_random_sweep(gpu, tuning):
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
             assert np.array_equal(got.class_candidates.cpu().numpy(), cc), it
             compared += 1
-    assert compared >= 60
+    assert compared >= 120
 
 
 def test_tile_kernel_random_sweep(gpu, tuning, c_oracle):

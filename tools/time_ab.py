@@ -21,7 +21,8 @@ for k, path in enumerate(a for a in sys.argv[1:] if a.endswith('.so')):
     for name in ('yh_detect_workspace_bytes', 'yh_detect_candidates', 'yh_set_tuning'):
         fn = getattr(lib, name); fn.restype, fn.argtypes = _abi.SIGNATURES[name]
     steps = int(os.environ.get('AB_STEPS', 0))
-    t = _abi.Tuning(row_steps=steps, stream_blocks=int(os.environ.get('AB_BLOCKS', 0)))
+    t = _abi.Tuning(row_steps=steps, stream_blocks=int(os.environ.get('AB_BLOCKS', 0)), rows_dense_min=int(os.environ.get('AB_DENSE_MIN', 0)),
+                    rows_probe=int(os.environ.get('AB_PROBE', 0)))
     assert lib.yh_set_tuning(ctypes.byref(t)) == 0
     libs.append((os.path.basename(path) + ('/steps%d' % steps if steps else ''), lib))
 cap, mb = int(os.environ.get('AB_CAP', 2048)), w['max_boxes']   # AB_CAP above the select stage's limit: the workgroup-tile variant

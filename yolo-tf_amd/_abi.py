@@ -48,7 +48,7 @@ class HeadConfig(ctypes.Structure):
 class Tuning(ctypes.Structure):
     """struct yh_tuning; 0 = the built-in default."""
     _fields_ = [(n, ctypes.c_int32) for n in ('detect_kernel', 'row_steps', 'stream_tile_kib', 'stream_buffers',
-                                              'stream_units', 'stream_blocks', 'stream_resident', 'rows_dense_min')]
+                                              'stream_units', 'stream_blocks', 'stream_resident', 'rows_dense_min', 'rows_probe')]
 
 
 _P = ctypes.c_void_p

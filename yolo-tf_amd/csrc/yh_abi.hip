@@ -189,10 +189,10 @@ constexpr uint64_t kRowsResidentGroups = 768;
 
 // Launch-plan knobs (yh_set_tuning): the one piece of process-wide state, plain words read with
 // relaxed atomics; 0 = the built-in default.
-constexpr int kTuneFields = 8;
+constexpr int kTuneFields = 9;
 std::atomic<int32_t> g_tuning[kTuneFields];
 enum { kTuneDetectKernel, kTuneRowSteps, kTuneStreamNi, kTuneStreamNbuf, kTuneStreamUnits, kTuneStreamBlocks, kTuneStreamResident,
-       kTuneRowsDenseMin };
+       kTuneRowsDenseMin, kTuneRowsProbe };
 
 long knob(int which, long fallback)
 {
@@ -253,18 +253,28 @@ uint32_t plan_stream(yh::StreamParams &p, int B, yh::StreamMode mode, int32_t ma
             p.sc[s].unit_base = upi;
             upi += (uint32_t)chunks;
         }
-        // A step is read whole (one contiguous span of 64 rows) instead of row by row once so many of its rows
-        // survive that the gathers would fetch about as many new cache lines as the span holds beyond the
-        // objectness lines already fetched: lines of the span 64 * 4K / 128 = 2K, of which min(64, 2K) came with
-        // the objectness column; a surviving row brings 4K / 128 new lines.  Streaming loads move a line
-        // more cheaply than gathers do, hence the factor 3/4.  (K = 85: 30 of 64 rows.)
+        // A unit is read whole (its steps as contiguous spans of 64 rows) instead of row by row once so many of its
+        // rows survive that the gathers would fetch as many cache lines as the spans hold: lines of a span
+        // 64 * 4K / 128 = 2K; row by row the objectness column costs min(64, 2K) lines per step and a surviving row
+        // 4K / 128 more (its objectness line does not survive in the cache until the row is read).  K = 85: 40 of 64
+        // rows.  The kernel decides per unit from sixteen sampled rows (10 of 16 at K = 85), and a launch lasts as
+        // long as its slowest unit: a unit read whole takes 32-36 us at K = 85 and four steps however many rows
+        // survive, a unit walked row by row 20 us plus 35 us times the share of surviving rows.  With this threshold
+        // a sparse launch (16 % surviving rows: 26 us) sees no unit read whole by chance (2e-5 per unit), and from
+        // 30 % on, where chance picks a few per launch, they end with the others.  (64 images of 10647 boxes, no
+        // candidates: row by row 20.1 / 25.5 / 39.5 / 50.7 / 54.8 us at 2 / 16 / 50 / 84 / 100 % surviving rows;
+        // with whole units 20.8 / 26.6 / 40.7 / 43.1 / 41.1 us, 235 MB of traffic at 100 % instead of 319 MB.)
+        // Rows no longer than a cache line: the column read fetches every line of the tensor anyway, a unit is read
+        // whole from 16 surviving rows in 64 on.
         {
             const double span_lines = 2.0 * p.K, col_lines = std::min(64.0, span_lines);
             const double per_row = std::max(0.25, p.K / 32.0);
-            long dm = std::lround(0.75 * (span_lines - col_lines) / per_row);
-            dm = std::min<long>(64, std::max<long>(4, dm));
+            long dm = std::lround((span_lines - col_lines) / per_row);
+            dm = std::min<long>(64, std::max<long>(16, dm));
             p.dense_min = (int32_t)knob(kTuneRowsDenseMin, dm);
+            p.dense_probe = knob(kTuneRowsProbe, 1) == 1 ? 1 : 0;   // tuning knob: 1 = sample (default), 2 = never
             p.dense_col_step = 256 % p.K;
+            p.dense_row_step = 256 / p.K;
         }
         p.units = (upi + waves - 1) / waves;                     // workgroups per image
         p.upi = (int32_t)(p.units * waves);
@@ -402,7 +412,7 @@ int yh_set_tuning(const yh_tuning *t)
 {
     const int32_t v[kTuneFields] = {t ? t->detect_kernel : 0, t ? t->row_steps : 0, t ? t->stream_tile_kib : 0,
                                     t ? t->stream_buffers : 0, t ? t->stream_units : 0, t ? t->stream_blocks : 0,
-                                    t ? t->stream_resident : 0, t ? t->rows_dense_min : 0};
+                                    t ? t->stream_resident : 0, t ? t->rows_dense_min : 0, t ? t->rows_probe : 0};
     for (int i = 0; i < kTuneFields; ++i)
         if (v[i] < 0) return fail(YH_ERR_INVALID_ARG, "tuning field %d is negative", i);
     for (int i = 0; i < kTuneFields; ++i) g_tuning[i].store(v[i], std::memory_order_relaxed);
@@ -420,6 +430,7 @@ int yh_get_tuning(yh_tuning *t)
     t->stream_blocks = g_tuning[kTuneStreamBlocks].load(std::memory_order_relaxed);
     t->stream_resident = g_tuning[kTuneStreamResident].load(std::memory_order_relaxed);
     t->rows_dense_min = g_tuning[kTuneRowsDenseMin].load(std::memory_order_relaxed);
+    t->rows_probe = g_tuning[kTuneRowsProbe].load(std::memory_order_relaxed);
     return YH_OK;
 }
 

@@ -107,8 +107,10 @@ struct StreamParams {
     int32_t wave_nbuf;      // wave-private variant: tile buffers per wavefront
     int32_t row_gather;     // 1: objectness-first variant (one work unit per wavefront, tiles_per_chunk steps of 64 rows)
     uint32_t units;         // objectness-first variant: workgroups per image (kRowsThreads / 64 units each)
-    int32_t dense_min;      // objectness-first variant: a step with at least this many surviving rows is read whole
+    int32_t dense_min;      // objectness-first variant: a unit of whose sampled rows this many in 64 survive is read whole (> 64: never)
+    int32_t dense_probe;    // ... 0: no unit is read whole; 1: a unit samples sixteen of its rows first
     int32_t dense_col_step; // ... (floats a wavefront covers per 16-byte load: 256) mod K
+    int32_t dense_row_step; // ... and 256 / K
     int32_t upi;            // wave-private variant: work units per image (all scales), <= kMaxUnitsPerImage
     uint32_t cuts;          // workgroup-tile variant: runs of tiles the pass is cut into (a workgroup's worth each)
     uint32_t grid_blocks;   // workgroup-tile variant: workgroups launched; fewer than `cuts`: each walks cuts
@@ -206,7 +208,7 @@ bool select_single_launch(int cand_cap, int num_classes, int max_boxes);   // k_
 bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
 bool select_fits_rows(const NmsParams &p);     // ... in a launch of the objectness-first variant
 constexpr int kRowsThreads = 256;           // objectness-first variant: four wavefronts per workgroup
-constexpr size_t kRowsLdsMax = 40 * 1024;   // four such workgroups per compute unit
+constexpr size_t kRowsLdsMax = 48 * 1024;   // three such workgroups per compute unit
 
 // ---- loss ------------------------------------------------------------------
 struct LossScale {

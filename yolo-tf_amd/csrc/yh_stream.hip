@@ -30,6 +30,7 @@
 // does not read the whole head; the default of yh_detect).
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include "yh_post.h"
 
 namespace yh {
@@ -65,8 +66,8 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
 
 // Box of row `row` (YOLOv3.py:340-348): yx = cell + 0.5 + sigmoid(t_yx),
 // hw = prior + exp(t_hw), corners scaled by the per-scale multiplier.
-__device__ __forceinline__ float4 decode_box(int P, const StreamScale &sc, float ty, float tx, float th,
-                                             float tw, uint32_t row)
+template <typename Scale>
+__device__ __forceinline__ float4 decode_box(int P, Scale &sc, float ty, float tx, float th, float tw, uint32_t row)
 {
     // row = (gy * grid_w + gx) * P + pi, taken apart without integer division: the product with
     // floor(2^32 / d) gives the quotient or one less, one comparison settles it
@@ -590,11 +591,290 @@ constexpr int kRowsPend = 64;                 // class logits past the prefilter
 constexpr int kRowsStage = 64;                // candidates (key, box) staged per wavefront before they are written out
 // per wavefront: staged boxes and keys, the survivors' ring (row, objectness), the pending class logits
 // (16 bytes each) and the box channels of the batch's sixteen rows
-constexpr size_t kRowsLdsWave = (size_t)kRowsStage * (16 + 8) + (size_t)kRowsList * 8 + (size_t)kRowsPend * 16 + (size_t)kRowsBatch * 16;
+// ... and the chunk buffer of a unit that is read whole: 4 KiB, four 16-byte loads per lane in flight
+constexpr uint32_t kRowsChunkSlots = 256;
+constexpr int kRowsDepth = 1;                 // chunks of a unit read whole that are in flight (in registers) ahead of the one in LDS
+constexpr size_t kRowsLdsWave = (size_t)kRowsStage * (16 + 8) + (size_t)kRowsList * 8 + (size_t)kRowsPend * 16 + (size_t)kRowsBatch * 16 +
+                                (size_t)kRowsChunkSlots * 16;
 constexpr size_t kRowsLds = (size_t)kRowsWaves * kRowsLdsWave;
 static_assert(kRowsLds <= kRowsLdsMax, "the select stage riding in the launch is planned against kRowsLdsMax");
 static_assert((kRowsList & (kRowsList - 1)) == 0 && kRowsList >= 64 + kRowsBatch, "ring indices are masked");
 static_assert(kRowsLdsWave % 16 == 0, "every wavefront's block starts 16-byte aligned");
+
+// ---- a unit read whole -----------------------------------------------------------------------------------
+// A step most of whose rows survive the objectness prefilter is better read whole: its 64 rows are one contiguous
+// span of 64 * K floats, which 16-byte loads at consecutive addresses move at streaming rate, where the row-by-row
+// walk asks for the same lines in 4-byte pieces, sixteen lanes per row, after the objectness column has already
+// fetched (and the cache has already dropped) a line of every row: a line per row fetched twice, 1.38 times the
+// tensor at 85 floats per row.  The choice is made once per unit (k_detect_rows, from sixteen sampled rows), and a
+// unit that is read whole runs here, in a function of its own that is NOT inlined: inlined, in whatever arrangement,
+// it changed the register allocation of the row-by-row walk (scalar registers spilled inside its loops; in one build
+// the next step's objectness logits, which are meant to stay in flight across a batch's gathers, landed in a
+// register the gathers' address arithmetic reused, so every gather waited for all loads before it: twice the time
+// at 50 % surviving rows).  The call costs the kernel a stack of 8 bytes per lane (the callee saves registers it
+// need not, the wavefront ends after it), which is 0.3 us per launch for the scratch set-up.
+// Its arguments arrive in vector registers and are uniform.
+//
+// A span starts at any 4-byte phase, so the loads cover the aligned window around it.  It travels in chunks of
+// 4 KiB, four 16-byte loads per lane: the next two chunks are on their way into registers while a chunk is looked
+// at in the wavefront's LDS buffer, and each is copied there when its turn comes (a unit is a chain of dependent round
+// trips, 87 KB at 85 floats per row and four steps: with one chunk ahead a unit read whole among units walked row by
+// row, which finish in half the time, was what the launch waited for) (loads into registers are waited for one by one
+// where they are used; LDS-DMA loads would make the compiler wait for all of them in front of every LDS read it
+// sees).  A row's objectness is its last float.  Every float of the chunk is compared with the prefilter, 16 bytes
+// per lane and turn; one that passes and is a class logit looks its row's objectness up in the chunk and, if that
+// passes too, joins the pending list; a full list (and the end of a step) gets the exact sigmoid product and
+// threshold, one logit per lane, and the box channels of those that pass are read back from memory (rare, and the
+// row's lines were fetched a moment ago).  A logit of the one row that straddles the chunk's end is queued with its
+// objectness to be read back from memory as well.
+typedef __attribute__((address_space(4))) const StreamParams kparams_t;    // the kernel's argument block
+typedef __attribute__((address_space(4))) const StreamScale kscale_t;
+// batch-slot field of a pending logit whose row's objectness is read back from memory before the exact test
+constexpr uint32_t kRowsObjKnown = 0u, kRowsObjFromMemory = 1u;
+
+__device__ __attribute__((noinline)) void rows_whole_unit(kparams_t *pv, int bv, uint32_t uiv, uint32_t ldsv)
+{
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(pv);
+    kparams_t &p = *reinterpret_cast<kparams_t *>(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)pa));
+    const int b = __builtin_amdgcn_readfirstlane(bv);
+    const uint32_t ui = (uint32_t)__builtin_amdgcn_readfirstlane((int)uiv);
+    unsigned char *at = (unsigned char *)(lds_float_t *)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ldsv);
+    const int lane = (int)(threadIdx.x & 63u);
+    float4 *s_box = reinterpret_cast<float4 *>(at);
+    at += (size_t)kRowsStage * 16;
+    uint4 *s_pend = reinterpret_cast<uint4 *>(at);             // class logit, objectness logit, row, class | kRowsObj* << 16
+    at += (size_t)kRowsPend * 16 + (size_t)kRowsBatch * 16;
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(at);
+    at += (size_t)kRowsStage * 8 + (size_t)kRowsList * 8;
+    float *s_chunk = reinterpret_cast<float *>(at);            // the chunk that is looked at
+
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && ui >= p.sc[i].unit_base) s = i;
+    kscale_t &sc = p.sc[s];
+    const uint32_t chunk = ui - sc.unit_base;
+    const int K = p.K, C = p.C;
+    const uint32_t steps = p.sc[0].tiles_per_chunk;
+    const float *img = sc.src + (long long)b * sc.span;
+    const uint32_t row_begin = chunk * steps * 64u;
+    uint32_t row_end = row_begin + steps * 64u;               // the caller found rows in this unit
+    if (row_end > sc.rows_img) row_end = sc.rows_img;
+    const float pf = p.prefilter, thr = p.thr;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const long long u = (long long)b * p.upi + ui;
+    WaveOut o;
+    o.ukeys = p.ukeys + u * kUnitSlots;
+    o.uboxes = reinterpret_cast<float4 *>(p.uboxes) + u * kUnitSlots;
+    o.cand = p.cand + (long long)b * p.cand_cap;
+    o.cand_box = reinterpret_cast<float4 *>(p.cand_box) + (long long)b * p.cand_cap;
+    o.img_count = p.img_count + b;
+    o.cand_cap = p.cand_cap;
+    int count = 0, emitted = 0, npend = 0;                    // as in k_detect_rows, wave-uniform
+#ifdef YH_ROWS_TRACE
+    unsigned long long wt0 = 0, wt1 = 0, wta = 0, wtb = 0, wait_sum = 0, scan_sum = 0, nchunks = 0;
+    YH_TRACE_NOW(wt0);
+#endif
+
+    auto settle = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        const bool live = lane < npend;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (live) e = s_pend[lane];
+        if ((e.w >> 16) == kRowsObjFromMemory) e.y = __float_as_uint(img[(size_t)e.z * K + C + 4]);
+        const float cf = decode_sigmoid(__uint_as_float(e.x)) * decode_sigmoid(__uint_as_float(e.y));
+        const bool hit = live && cf >= thr;
+        const unsigned long long hm = __ballot(hit);
+        npend = 0;
+        if (hm == 0ull) return;
+        const int add = __builtin_popcountll(hm);
+        if (count + add > kRowsStage) wave_flush(o, s_keys, s_box, count, emitted, lane);
+        if (hit) {
+            const float *rp = img + (size_t)e.z * K + C;
+            const int pos = count + __builtin_popcountll(hm & lanes_below);
+            s_keys[pos] = make_key((int)(e.w & 0xffffu), cf, (int)(sc.row_base + e.z));
+            s_box[pos] = decode_box(p.P, sc, rp[0], rp[1], rp[2], rp[3], e.z);
+        }
+        count += add;
+    };
+    auto pend = [&](bool hit, int c, float x, float ob, uint32_t row, uint32_t how) {
+        const unsigned long long hm = __ballot(hit);
+        if (hm == 0ull) return;
+        const int add = __builtin_popcountll(hm);
+        if (npend + add > kRowsPend) settle();
+        if (hit)
+            s_pend[npend + __builtin_popcountll(hm & lanes_below)] =
+                make_uint4(__float_as_uint(x), __float_as_uint(ob), row, (uint32_t)c | (how << 16));
+        npend += add;
+    };
+
+    // 32-bit indices relative to the image's 16-byte slot: the image starts at any 4-byte phase of it
+    const uint32_t img_phase = (uint32_t)(reinterpret_cast<uintptr_t>(img) >> 2) & 3u;
+    const float4 *img4 = reinterpret_cast<const float4 *>(img - img_phase);
+    // floats from the image's slot to the end of the tensor, saturated (only a window that reaches the tensor's
+    // end looks at it, and such a window starts less than 2^32 floats before it)
+    const unsigned long long img_floats64 = (unsigned long long)(p.B - b) * sc.span + img_phase;
+    const uint32_t img_floats = img_floats64 > 0xffffffffull ? 0xffffffffu : (uint32_t)img_floats64;
+    const uint32_t behind = (uint32_t)(K - C);                // columns C .. K-1 hold no class logit
+    const float kNaN = __builtin_nanf("");
+
+    for (uint32_t row0 = row_begin; row0 < row_end; row0 += 64u) {
+        const uint32_t nrows = row_end - row0 < 64u ? row_end - row0 : 64u;
+        const uint32_t nfl = nrows * (uint32_t)K;             // floats of the span
+        const uint32_t a0 = img_phase + row0 * (uint32_t)K;   // the span's first float
+        const int sh = (int)(a0 & 3u);
+        const uint32_t wslots = ((uint32_t)sh + nfl + 3u) >> 2;
+        const float4 *src4 = img4 + (a0 >> 2);                // first 16-byte slot of the window
+        const int tail_valid = (int)(nfl + (uint32_t)sh) - 4 * (int)(wslots - 1u);   // floats of the last slot inside the span: 1..4
+        int fi0 = 4 * lane - sh;                              // the lane's first float, relative to the span; -3 .. -1: before it
+        int rr0 = fi0 >= 0 ? (int)__umulhi((uint32_t)fi0, p.magic_k) : -1;   // its row of the step and its column
+        int col0 = fi0 >= 0 ? fi0 - rr0 * K : fi0 + K;
+        const uint32_t left_f = img_floats - (a0 & ~3u);      // floats from the window's start to the tensor's end
+        const uint32_t full = (left_f >> 2) < wslots ? (left_f >> 2) : wslots;   // slots to read as 16 bytes
+        // the next kRowsDepth chunks travel in registers while this one is looked at in LDS
+        v4f_t nx[kRowsDepth][kRowsChunkSlots / 64];
+        auto request = [&](v4f_t (&dst)[kRowsChunkSlots / 64], uint32_t w0) {
+#pragma unroll
+            for (int j = 0; j < (int)kRowsChunkSlots / 64; ++j) {
+                const uint32_t w = w0 + (uint32_t)j * 64u + (uint32_t)lane;
+                dst[j] = (v4f_t){0.0f, 0.0f, 0.0f, 0.0f};
+                if (w < full) dst[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(src4 + w));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < kRowsDepth; ++d)
+            if ((uint32_t)d * kRowsChunkSlots < wslots) request(nx[d], (uint32_t)d * kRowsChunkSlots);
+        for (uint32_t wd = 0; wd < wslots; wd += kRowsDepth * kRowsChunkSlots) {
+#pragma unroll
+        for (int d = 0; d < kRowsDepth; ++d) {
+            const uint32_t w0 = wd + (uint32_t)d * kRowsChunkSlots;
+            if (w0 >= wslots) break;                          // wave-uniform
+            const uint32_t cs = wslots - w0 < kRowsChunkSlots ? wslots - w0 : kRowsChunkSlots;   // slots of this chunk
+            __builtin_amdgcn_wave_barrier();
+#ifdef YH_ROWS_TRACE
+            YH_TRACE_NOW(wta);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            YH_TRACE_NOW(wtb);
+            wait_sum += wtb - wta;
+            ++nchunks;
+#endif
+#pragma unroll
+            for (int j = 0; j < (int)kRowsChunkSlots / 64; ++j)
+                reinterpret_cast<v4f_t *>(s_chunk)[j * 64 + lane] = nx[d][j];
+            if (w0 + kRowsDepth * kRowsChunkSlots < wslots) request(nx[d], w0 + kRowsDepth * kRowsChunkSlots);
+            if (full < w0 + cs) {                             // the tensor's last, partial slot: 1..3 floats
+                if ((uint32_t)lane < (left_f & 3u))
+                    s_chunk[(full - w0) * 4u + (uint32_t)lane] = reinterpret_cast<const float *>(src4 + full)[lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int cbase = 4 * (int)w0 - sh;               // index, relative to the span, of the buffer's first float
+            int r_hi = (int)__umulhi((uint32_t)(cbase + 4 * (int)cs), p.magic_k);   // rows that end before the chunk does
+            r_hi = r_hi < (int)nrows ? r_hi : (int)nrows;
+            const int nu = (int)((cs + 63u) >> 6);
+#ifdef YH_ROWS_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            YH_TRACE_NOW(wta);
+#endif
+            // First the whole chunk at once: is there a float anywhere in it that reaches the prefilter in a column
+            // that may hold a class logit?  Four independent 16-byte reads and comparison chains per lane (a
+            // wavefront on its own SIMD advances at the latency of dependent instructions, not at their issue
+            // rate: one slot per turn took 420 cycles a turn).  Stale floats behind a short chunk and the floats
+            // around the span can only make this answer yes.  Usually it is no, and the chunk is done.
+            {
+                float mx = kNaN;
+                int cc = col0;
+#pragma unroll
+                for (int t = 0; t < (int)kRowsChunkSlots / 64; ++t) {
+                    const float4 x = reinterpret_cast<const float4 *>(s_chunk)[t * 64 + lane];
+                    const uint32_t t0 = (uint32_t)(cc - C);
+                    const float m0 = t0 >= behind ? x.x : kNaN, m1 = t0 + 1u >= behind ? x.y : kNaN;
+                    const float m2 = t0 + 2u >= behind ? x.z : kNaN, m3 = t0 + 3u >= behind ? x.w : kNaN;
+                    mx = fmaxf(mx, fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+                    cc += p.dense_col_step;
+                    cc = cc >= K ? cc - K : cc;
+                }
+                if (__ballot(mx >= pf) == 0ull) {
+                    for (int t = 0; t < nu; ++t) {            // the lane's place after the chunk
+                        rr0 += p.dense_row_step;
+                        col0 += p.dense_col_step;
+                        if (col0 >= K) { col0 -= K; ++rr0; }
+                    }
+#ifdef YH_ROWS_TRACE
+                    YH_TRACE_NOW(wtb);
+                    scan_sum += wtb - wta;
+#endif
+                    continue;
+                }
+            }
+#pragma unroll 1
+            for (int t = 0; t < nu; ++t) {
+                const uint32_t wl = (uint32_t)t * 64u + (uint32_t)lane;     // the lane's slot of the chunk
+                float4 x = reinterpret_cast<const float4 *>(s_chunk)[wl];
+                // Conservative and cheap, because it runs for every 16 bytes of the tensor: a float counts when its
+                // column (that of the lane's first float plus its place) is not one of the K - C columns behind the
+                // class logits (a column that wrapped into the next row passes too; the exact row and column follow
+                // for the few floats that get further), anything else is replaced by NaN (which no comparison passes, whatever the prefilter, and
+                // which the maximum ignores); when no lane's largest
+                // float reaches the prefilter, which is the usual case, the turn ends here.
+                const uint32_t t0 = (uint32_t)(col0 - C);
+                x.x = t0 >= behind ? x.x : kNaN;
+                x.y = t0 + 1u >= behind ? x.y : kNaN;
+                x.z = t0 + 2u >= behind ? x.z : kNaN;
+                x.w = t0 + 3u >= behind ? x.w : kNaN;
+                if ((w0 == 0u && t == 0) || (t == nu - 1 && w0 + cs == wslots)) {   // wave-uniform: the window's first and last slots
+                    uint32_t ok = wl < cs ? 0xfu : 0u;        // floats of the window outside the span do not count
+                    ok = w0 + wl == wslots - 1u ? (1u << tail_valid) - 1u : ok;
+                    ok = w0 + wl == 0u ? ok & (0xfu << sh) : ok;
+                    x.x = (ok & 1u) ? x.x : kNaN;
+                    x.y = (ok & 2u) ? x.y : kNaN;
+                    x.z = (ok & 4u) ? x.z : kNaN;
+                    x.w = (ok & 8u) ? x.w : kNaN;
+                }
+                uint32_t bits = 0u;
+                if (__ballot(fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)) >= pf) != 0ull)
+                    bits = (x.x >= pf ? 1u : 0u) | (x.y >= pf ? 2u : 0u) | (x.z >= pf ? 4u : 0u) | (x.w >= pf ? 8u : 0u);
+                while (__ballot(bits != 0u) != 0ull) {
+                    const int i = bits != 0u ? __builtin_ctz(bits) : 0;
+                    const float xi = i == 0 ? x.x : i == 1 ? x.y : i == 2 ? x.z : x.w;
+                    int rr = rr0, c = col0 + i;
+                    if (c >= K) { c -= K; ++rr; }
+                    bool hit = bits != 0u && c < C;
+                    float obr = 0.0f;
+                    uint32_t how = kRowsObjKnown;
+                    if (hit) {
+                        if (rr < r_hi) {
+                            obr = s_chunk[rr * K + K - 1 - cbase];
+                            hit = obr >= pf;
+                        } else {
+                            how = kRowsObjFromMemory;
+                        }
+                    }
+                    pend(hit, c, xi, obr, row0 + (uint32_t)rr, how);
+                    bits &= bits - 1u;
+                }
+                rr0 += p.dense_row_step;
+                col0 += p.dense_col_step;
+                if (col0 >= K) { col0 -= K; ++rr0; }
+            }
+#ifdef YH_ROWS_TRACE
+            YH_TRACE_NOW(wtb);
+            scan_sum += wtb - wta;
+#endif
+        }
+        }
+        if (npend > 0) settle();
+    }
+    if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);
+    if (lane >= emitted && lane < kUnitSlots) o.ukeys[lane] = kEmptySlot;        // the unit's unused slots
+#ifdef YH_ROWS_TRACE
+    YH_TRACE_STAMP(wt1);
+    if (lane == 0 && u < (long long)kTraceWaves) {            // measurement build: this unit's record, by unit number
+        unsigned long long *tr = g_rows_trace + u * kTraceWords;
+        tr[0] = wt0; tr[1] = wt1; tr[2] = wait_sum; tr[3] = scan_sum; tr[4] = nchunks; tr[5] = 0; tr[6] = 0; tr[7] = ~0ull;
+    }
+#endif
+}
 
 __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams p, const NmsParams q)
 {
@@ -754,70 +1034,68 @@ __global__ __launch_bounds__(kRowsThreads) void k_detect_rows(const StreamParams
         YH_TRACE_NOW(trC);
     };
 
-    // A round is kRowsAhead steps whose objectness logits are requested together; the next round's are
-    // in flight while this round's are looked at.  Launch plans aim at one round per unit, with every
-    // workgroup of the launch resident: no wavefront then waits for a second memory round trip before
-    // its survivors' gathers.  One more pass of the loop, after the last round, works the ring empty:
-    // written this way the batch code exists once in the kernel.
+    // The unit's steps, in one of two ways, chosen once per unit (a unit that mixed them would keep the state of
+    // both alive across each other's code, and the row-by-row walk, the common case, would pay for it in registers).
+    // The unit first looks at the objectness of sixteen of its rows, spread evenly over its steps: sixteen lines.
+    // When p.dense_min in 64 of them or more pass, every step of the unit is read whole, with no objectness column
+    // requested at all (the column read of a step that is then read whole is wasted traffic: a line per row fetched
+    // twice, 1.38 times the tensor at 85 floats per row, because the lines do not survive in the cache until the
+    // rows are read).
+    // Otherwise (what a detector's head looks like) the walk is row by row: the objectness logits of step t + 1 are
+    // requested before those of step t are looked at; rows that pass are queued, and as soon as a whole batch is
+    // queued it is worked on (with one step requested ahead little stands between a batch's gathers and the memory
+    // system; waiting until the ring could not take another step was 2 % slower from 16 % surviving rows up and no
+    // faster below).  One more pass of the loop, after the last step, works the ring empty: written this way the
+    // batch code exists once in the kernel.
+    static_assert(kRowsAhead == 1, "one step's objectness logits are requested ahead");
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
     (void)tr0; (void)tr1; (void)tr2; (void)tr3; (void)tr4;
     int trace_left = 0;
     (void)trace_left;
     YH_TRACE_NOW(tr0);
-    float obj_n[kRowsAhead];
-#pragma unroll
-    for (int k = 0; k < kRowsAhead; ++k)
-        obj_n[k] = (uint32_t)k < nsteps ? objectness(row_begin + (uint32_t)k * 64u + (uint32_t)lane) : kNoRow;
-    for (uint32_t t = 0;; t += kRowsAhead) {
-        const bool last = t >= nsteps;                        // wave-uniform
-        float obj_c[kRowsAhead];
-        unsigned long long masks[kRowsAhead];
-#pragma unroll
-        for (int k = 0; k < kRowsAhead; ++k) {
-            obj_c[k] = obj_n[k];
-            masks[k] = 0ull;
+    bool dense = false;                                       // wave-uniform
+    if (nsteps > 0u && p.dense_min <= 64) {
+        if (p.dense_probe == 1) {
+            const uint32_t prow = row_begin + (uint32_t)lane * (nsteps * 4u);   // every (4 * steps)-th row: 16 lanes span the unit
+            const float po = lane < 16 ? objectness(prow) : kNoRow;
+            const int have = __builtin_popcountll(__ballot(lane < 16 && prow < row_end));
+            const int pass = __builtin_popcountll(__ballot(po >= pf));
+            dense = pass * 64 >= p.dense_min * have;
         }
-        if (!last) {
-#pragma unroll
-            for (int k = 0; k < kRowsAhead; ++k) {
-                const uint32_t tn = t + (uint32_t)(kRowsAhead + k);
-                obj_n[k] = tn < nsteps ? objectness(row_begin + tn * 64u + (uint32_t)lane) : kNoRow;
-            }
-#pragma unroll
-            for (int k = 0; k < kRowsAhead; ++k) masks[k] = __ballot(obj_c[k] >= pf);
-#ifdef YH_ROWS_TRACE
-            if (t == 0) { asm volatile("" ::"s"(masks[0])); YH_TRACE_NOW(tr1); }
-#endif
-        } else {
-            YH_TRACE_STAMP(tr2);
-            trace_left = tail - head;
-        }
-#pragma unroll 1
-        for (int k = 0; k < (last ? 1 : kRowsAhead); ++k) {
+    }
+    if (dense) {
+        // out of line, with nothing of this function alive across the call: the walk below keeps its registers
+        rows_whole_unit((kparams_t *)__builtin_amdgcn_kernarg_segment_ptr(), b, ui,
+                        (uint32_t)(uintptr_t)(lds_float_t *)(void *)(s_dyn + (size_t)wave * kRowsLdsWave));
+        return;
+    } else {
+        float obj_next = nsteps > 0u ? objectness(row_begin + (uint32_t)lane) : kNoRow;
+        for (uint32_t t = 0;; ++t) {
+            const bool last = t >= nsteps;                    // wave-uniform
             if (!last) {
-                unsigned long long mask = masks[0];
-                float ob = obj_c[0];
-#pragma unroll
-                for (int i = 1; i < kRowsAhead; ++i) {
-                    mask = k == i ? masks[i] : mask;
-                    ob = k == i ? obj_c[i] : ob;
-                }
+                const uint32_t row0 = row_begin + t * 64u;
+                const float ob = obj_next;
+                obj_next = t + 1u < nsteps ? objectness(row0 + 64u + (uint32_t)lane) : kNoRow;
+                const unsigned long long mask = __ballot(ob >= pf);
+#ifdef YH_ROWS_TRACE
+                if (t == 0) { asm volatile("" ::"s"(mask)); YH_TRACE_NOW(tr1); }
+#endif
                 if (mask) {
                     if ((mask >> lane) & 1ull) {
                         const int e = (tail + __builtin_popcountll(mask & lanes_below)) & (kRowsList - 1);
-                        s_lrow[e] = row_begin + (t + (uint32_t)k) * 64u + (uint32_t)lane;
+                        s_lrow[e] = row0 + (uint32_t)lane;
                         s_lobj[e] = ob;
                     }
                     tail += __builtin_popcountll(mask);
                 }
+            } else {
+                YH_TRACE_STAMP(tr2);
+                trace_left = tail - head;
             }
-            // mid-walk as soon as a whole batch is queued (with one step requested ahead little stands between a
-            // batch's gathers and the memory system; waiting until the ring could not take another step was
-            // 2 % slower from 16 % surviving rows up and no faster below)
             const int keep = last ? 0 : kRowsBatch - 1;
             while (tail - head > keep) work(tail - head < kRowsBatch ? tail - head : kRowsBatch);
+            if (last) break;
         }
-        if (last) break;
     }
     YH_TRACE_STAMP(tr3);
     if (count > 0) wave_flush(o, s_keys, s_box, count, emitted, lane);

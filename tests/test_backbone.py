@@ -183,3 +183,50 @@ def test_yolov2_trains_end_to_end_from_images():
         last = float(net.train_one_epoch(1e-3))
     assert isinstance(net.head_provider, bb.Darknet19Head)
     assert np.isfinite(first) and np.isfinite(last) and last < first
+
+
+# ---- the convolution building blocks against an independent NumPy float64 restatement -----------------
+# tests/golden/conv_chain.npz comes from tests/golden/make_conv_golden.py, which restates _conv_layer, _bn,
+# _darknet_block and _yolo3_header (YOLOv3.py:396-417, 487-517) from the source text with NumPy only.  On
+# the GPU the modules run on MIOpen in channels_last memory, which is what feeds the HIP kernels.
+def _load_conv_golden():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'conv_chain.npz')
+    return np.load(path)
+
+
+def _fill(module, gold, prefix):
+    state = module.state_dict()
+    for name in state:
+        if name.endswith(('conv.weight', 'conv.bias', 'bn.weight', 'bn.bias')):
+            state[name] = torch.from_numpy(gold[prefix + name]).to(state[name].dtype)
+    module.load_state_dict(state)
+    return module.train()                                     # batch statistics, as the reference's graph has them
+
+
+def _conv_blocks_match(dev, tol):
+    gold = _load_conv_golden()
+    t = lambda a: torch.from_numpy(gold[a]).float().to(dev).contiguous(memory_format=torch.channels_last)
+    close = lambda got, name: np.testing.assert_allclose(got.detach().float().cpu().numpy(), gold[name], rtol=tol, atol=tol,
+                                                         err_msg=name)
+    x = t('layer.x')
+    for name, cout, k, stride, act in (('c3', 7, 3, 1, True), ('c3s2', 6, 3, 2, True), ('c1', 4, 1, 1, False)):
+        layer = _fill(bb.ConvBN(5, cout, k, stride, activation=act), gold, 'layer.%s.' % name).to(dev)
+        close(layer(x), 'layer.%s.y' % name)
+    block = _fill(bb.DarknetBlock(4, 8, 2), gold, 'block.').to(dev)
+    close(block(t('block.x')), 'block.y')
+    header = _fill(bb.Yolo3Header(6, 8, 11, pyramid_channels=5), gold, 'header.').to(dev)
+    pred, conv5 = header(t('header.bottom'), t('header.pyramid'))
+    close(conv5, 'header.conv5')
+    close(pred, 'header.pred')
+    assert pred.shape == (2, 11, 7, 6)
+
+
+def test_conv_blocks_match_the_numpy_restatement_cpu():
+    _conv_blocks_match(torch.device('cpu'), 1e-4)
+
+
+@pytest.mark.gpu
+def test_conv_blocks_match_the_numpy_restatement_on_miopen(gpu):
+    """The same on the MI355X (MIOpen convolutions, channels_last): 1e-4, fp32 against float64."""
+    _conv_blocks_match(gpu, 1e-4)

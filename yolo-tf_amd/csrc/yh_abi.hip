@@ -140,13 +140,48 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     return w;
 }
 
-// yh_detect's workspace for a streaming plan: the slot-writing kernels followed by the
-// single-launch select stage never touch the boxes-by-row array, the largest part by far.
+// yh_detect's workspace for a streaming plan.  The boxes-by-row array, the largest part by far, is only needed
+// between a slot-writing kernel and the multi-launch select stage (which looks boxes up by row: k_bin copies
+// the slots' boxes there); the workgroup-tile kernel leaves no boxes at all, the stages behind it decode the
+// box of a row they look at from the head tensors.
 DetectWs carve_for_plan(void *base, const yh::StreamParams &p, int64_t B, int64_t cap, int64_t mb)
 {
     const bool slots = p.wave_ni || p.row_gather;
-    const bool row_boxes = !slots || !yh::select_single_launch((int)cap, p.C, (int)mb);
+    const bool row_boxes = slots && !yh::select_single_launch((int)cap, p.C, (int)mb);
     return carve_detect(base, B, p.N, p.C, cap, mb, row_boxes, slots, p.upi);
+}
+
+// The workgroup-tile streaming kernel leaves no boxes: the select stage decodes the boxes it looks at from the
+// head tensors.  When the two stages are separate calls (yh_detect_candidates / yh_detect_select, or a batch's
+// select stage riding in the next call of yh_detect_pipelined) the select stage has no head argument of its
+// own: the library remembers, per workspace, the head tensors of the last streaming call on it.  A small
+// table; the oldest entry goes when it is full.
+struct WorkspaceHeads { const void *ws; const float *head[YH_MAX_SCALES]; };
+constexpr int kWorkspaceHeads = 64;
+std::mutex g_ws_heads_mu;
+WorkspaceHeads g_ws_heads[kWorkspaceHeads];
+unsigned g_ws_heads_next = 0;
+
+void remember_heads(const void *ws, const float *const *heads, int S)
+{
+    std::lock_guard<std::mutex> lock(g_ws_heads_mu);
+    int at = -1;
+    for (int i = 0; i < kWorkspaceHeads && at < 0; ++i)
+        if (g_ws_heads[i].ws == ws) at = i;
+    if (at < 0) at = (int)(g_ws_heads_next++ % kWorkspaceHeads);
+    g_ws_heads[at].ws = ws;
+    for (int s = 0; s < YH_MAX_SCALES; ++s) g_ws_heads[at].head[s] = s < S ? heads[s] : nullptr;
+}
+
+bool recall_heads(const void *ws, const float **heads)
+{
+    std::lock_guard<std::mutex> lock(g_ws_heads_mu);
+    for (int i = 0; i < kWorkspaceHeads; ++i)
+        if (g_ws_heads[i].ws == ws) {
+            for (int s = 0; s < YH_MAX_SCALES; ++s) heads[s] = g_ws_heads[i].head[s];
+            return true;
+        }
+    return false;
 }
 
 int check_nms_args(int32_t batch, float iou_thr, int32_t max_boxes, int32_t max_cand, const void *ws,
@@ -613,6 +648,21 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
     d.q = make_nms_params(w, batch, cfg->num_classes, (int32_t)N, w.boxes, iou_threshold,
                           nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
                           out_class, out_index, out_class_candidates, status);
+    if (!w.boxes && !(p.wave_ni || p.row_gather)) {
+        // boxes by row are decoded from the head tensors where they are looked at: those of this call, or of the
+        // streaming call that filled this workspace
+        d.q.src_P = p.P; d.q.src_K = p.K; d.q.src_C = p.C; d.q.src_S = p.S;
+        std::memcpy(d.q.src, p.sc, sizeof(d.q.src));
+        if (want_stream) {
+            remember_heads(workspace, heads, p.S);
+        } else {
+            const float *prev[YH_MAX_SCALES];
+            if (!recall_heads(workspace, prev))
+                return fail(YH_ERR_INVALID_ARG, "no streaming call on this workspace is on record: its select stage reads the "
+                            "boxes it needs from that call's head tensors");
+            for (int s = 0; s < p.S; ++s) d.q.src[s].src = prev[s];
+        }
+    }
     if (p.wave_ni || p.row_gather) {          // candidates arrive with slot-indexed boxes
         d.q.upi = p.upi;
         d.q.ukeys = w.ukeys;

@@ -128,6 +128,41 @@ struct StreamParams {
     StreamScale sc[YH_MAX_SCALES];
 };
 
+// Box of row `row` (YOLOv3.py:340-348): yx = cell + 0.5 + sigmoid(t_yx),
+// hw = prior + exp(t_hw), corners scaled by the per-scale multiplier.
+template <typename Scale>
+__device__ __forceinline__ float4 decode_box(int P, Scale &sc, float ty, float tx, float th, float tw, uint32_t row)
+{
+    // row = (gy * grid_w + gx) * P + pi, taken apart without integer division: the product with
+    // floor(2^32 / d) gives the quotient or one less, one comparison settles it
+    uint32_t cell = __umulhi(row, sc.magic_p);
+    uint32_t pi = row - cell * (uint32_t)P;
+    if (pi >= (uint32_t)P) { pi -= (uint32_t)P; ++cell; }
+    uint32_t gy = __umulhi(cell, sc.magic_w);
+    uint32_t gx = cell - gy * sc.grid_w;
+    if (gx >= sc.grid_w) { gx -= sc.grid_w; ++gy; }
+    // The prior of a per-lane index: a uniform walk over the table (scalar reads of the parameter block
+    // and a select each) instead of an indexed read, which would be a vector load from memory with a
+    // full round trip in the middle of the decode.
+    float ph = sc.prior_hw[0][0], pw = sc.prior_hw[0][1];
+    for (int k = 1; k < P; ++k) {
+        const float kh = sc.prior_hw[k][0], kw = sc.prior_hw[k][1];
+        ph = pi == (uint32_t)k ? kh : ph;
+        pw = pi == (uint32_t)k ? kw : pw;
+    }
+    const float by = ((float)gy + 0.5f) + decode_sigmoid(ty);
+    const float bx = ((float)gx + 0.5f) + decode_sigmoid(tx);
+    const float bh = ph + decode_exp(th);
+    const float bw = pw + decode_exp(tw);
+    const float m = sc.mult;
+    float4 o;
+    o.x = (by - bh / 2.0f) * m;
+    o.y = (bx - bw / 2.0f) * m;
+    o.z = (by + bh / 2.0f) * m;
+    o.w = (bx + bw / 2.0f) * m;
+    return o;
+}
+
 // Raises a kernel's dynamic-LDS limit on the current device when `bytes` needs it (cached).
 hipError_t raise_lds_limit(const void *kernel, size_t bytes);
 constexpr size_t kLdsPerWorkgroupMax = 160 * 1024;   // LDS of one gfx950 compute unit
@@ -182,7 +217,9 @@ struct NmsParams {
     int32_t *kept_cnt;                 // [B][C]
     int32_t *kept_row;                 // [B][C][max_boxes]
     float *kept_score;                 // [B][C][max_boxes]
-    const float *boxes;                // [B][N][4] indexed by box row
+    const float *boxes;                // [B][N][4] indexed by box row; null: a box is decoded from the head tensors (src)
+    int32_t src_P, src_K, src_C, src_S;   // with boxes == null: the head's geometry, as in StreamParams
+    StreamScale src[YH_MAX_SCALES];
     float *boxes_fill;                 // same array when the multi-launch path has to fill it from the
                                        // slot-indexed boxes, else null
     int32_t *out_count;                // [B]
@@ -193,6 +230,32 @@ struct NmsParams {
     int32_t *out_class_candidates;     // [B][C] or null
     int32_t *status;
 };
+
+// The box of box row n of image b for the stages behind the streaming pass: from the caller's or the workspace's
+// array by row, or decoded from the head tensors where the streaming pass left no such array (YOLOv3.py:340-348;
+// the same function and operands as every other decode of the library: the same bits).
+__device__ __forceinline__ float4 row_box(const NmsParams &p, int b, int n)
+{
+    if (p.boxes) return reinterpret_cast<const float4 *>(p.boxes)[(long long)b * p.N + n];
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.src_S && (uint32_t)n >= p.src[i].row_base) s = i;
+    // the scale of a per-lane row: uniform reads of the parameter block and selects
+    const float *src = p.src[0].src;
+    uint32_t rows_img = p.src[0].rows_img, row_base = 0u;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.src_S && s == i) { src = p.src[i].src; rows_img = p.src[i].rows_img; row_base = p.src[i].row_base; }
+    const uint32_t row = (uint32_t)n - row_base;
+    const float *rp = src + ((long long)b * rows_img + row) * p.src_K + p.src_C;
+    const float ty = rp[0], tx = rp[1], th = rp[2], tw = rp[3];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < YH_MAX_SCALES; ++i)
+        if (i < p.src_S && s == i) o = decode_box(p.src_P, p.src[i], ty, tx, th, tw, row);
+    return o;
+}
 
 // single-launch shape of the candidates -> detections stage (k_post)
 constexpr int kPostCap = 2048;          // candidates per image

@@ -329,7 +329,8 @@ struct BlockNmsLds {
     int kept;
 };
 
-__device__ inline int block_nms(const unsigned long long *keys, int cnt, const float4 *boxes4, float (*kbox)[5],
+template <typename BoxOf>
+__device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf box_of, float (*kbox)[5],
                                 float thr, int max_boxes, int32_t *krow, float *kscore, BlockNmsLds &l)
 {
     static_assert(kSegThreads == 256, "sixteen columns of the bit matrix per wavefront");
@@ -341,7 +342,7 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, const f
         const unsigned long long key = valid ? keys[i] : 0ull;
         const int n = key_row(key);
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) bx = boxes4[n];
+        if (valid) bx = box_of(n);
         const float ymin = fminf(bx.x, bx.z), xmin = fminf(bx.y, bx.w);
         const float ymax = fmaxf(bx.x, bx.z), xmax = fmaxf(bx.y, bx.w);
         const float area = (ymax - ymin) * (xmax - xmin);
@@ -413,14 +414,14 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         return;
     }
     unsigned long long *keys = p.seg_keys + (long long)b * p.cand_cap + p.seg_off[seg];
-    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+    auto box_of = [&](int n) { return row_box(p, b, n); };
     auto walk = [&](const unsigned long long *sorted, int n) {          // wave 0
-        return wave_nms<false>(sorted, n, boxes4, nullptr, s_kbox, p.iou_thr, p.max_boxes,
+        return wave_nms<false>(sorted, n, box_of, nullptr, s_kbox, p.iou_thr, p.max_boxes,
                                p.kept_row + (long long)seg * p.max_boxes,
                                p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
     };
     auto block_walk = [&](const unsigned long long *sorted, int n) {    // the whole workgroup
-        return block_nms(sorted, n, boxes4, s_kbox, p.iou_thr, p.max_boxes,
+        return block_nms(sorted, n, box_of, s_kbox, p.iou_thr, p.max_boxes,
                          p.kept_row + (long long)seg * p.max_boxes,
                          p.kept_score + (long long)seg * p.max_boxes, s_walk);
     };
@@ -490,7 +491,6 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int
     __syncthreads();
     block_exclusive_scan<kFinThreads, YH_MAX_CLASSES / kFinThreads>(s_off, C, s_wave);
     const long long cap = (long long)C * mb;
-    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
     const long long e_end = (long long)(part + 1) * kFinSlots < cap ? (long long)(part + 1) * kFinSlots : cap;
     for (long long e = (long long)part * kFinSlots + tid; e < e_end; e += kFinThreads) {
         const int c = (int)(e / mb), j = (int)(e - (long long)c * mb);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int
             const long long dst = (long long)b * cap + s_off[c] + j;
             const int n = p.kept_row[src];
             p.out_scores[dst] = p.kept_score[src];
-            reinterpret_cast<float4 *>(p.out_boxes)[dst] = boxes4[n];
+            reinterpret_cast<float4 *>(p.out_boxes)[dst] = row_box(p, b, n);
             p.out_class[dst] = c;
             p.out_index[dst] = n;
         }

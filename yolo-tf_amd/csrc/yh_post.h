@@ -143,10 +143,10 @@ __device__ inline void cand_for_each(const NmsParams &p, int b, int list_raw, F 
     const int nl = list_raw < p.cand_cap ? list_raw : p.cand_cap;
     const unsigned long long *cand = p.cand + (long long)b * p.cand_cap;
     const float4 *cb = p.cand_box ? reinterpret_cast<const float4 *>(p.cand_box) + (long long)b * p.cand_cap : nullptr;
-    const float4 *boxes4 = reinterpret_cast<const float4 *>(p.boxes) + (long long)b * p.N;
+
     for (int i = tid; i < nl; i += THREADS) {
         const unsigned long long k = cand[i];
-        f(k, WANT_BOX ? (cb ? cb[i] : boxes4[key_row(k)]) : zero);
+        f(k, WANT_BOX ? (cb ? cb[i] : row_box(p, b, key_row(k))) : zero);
     }
 }
 
@@ -216,12 +216,12 @@ __device__ __forceinline__ unsigned long long resolve_tile(unsigned long long al
 // keys[0..cnt): sorted candidate keys (LDS or global); kbox: room for max_boxes
 // selected boxes (5 floats each) private to this wavefront.  Returns the number
 // selected.
-//   IN_LDS = false: boxes are gathered from boxes4[row]; the selection goes to
+//   IN_LDS = false: the box of row n is box_of(n); the selection goes to
 //                   krow / kscore (global, one list per segment);
 //   IN_LDS = true : boxes_seg[i] is the box of keys[i] (LDS); the selection goes
 //                   to kpos as positions pos_base + i (LDS).
-template <bool IN_LDS>
-__device__ inline int wave_nms(const unsigned long long *keys, int cnt, const float4 *boxes4,
+template <bool IN_LDS, typename BoxOf>
+__device__ inline int wave_nms(const unsigned long long *keys, int cnt, BoxOf box_of,
                                const float4 *boxes_seg, float (*kbox)[5], float thr, int max_boxes,
                                int32_t *krow, float *kscore, uint16_t *kpos, int pos_base)
 {
@@ -233,7 +233,7 @@ __device__ inline int wave_nms(const unsigned long long *keys, int cnt, const fl
         const unsigned long long key = valid ? keys[i] : 0ull;
         const int n = key_row(key);
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) bx = IN_LDS ? boxes_seg[i] : boxes4[n];
+        if (valid) bx = IN_LDS ? boxes_seg[i] : box_of(n);
         const float ymin = fminf(bx.x, bx.z), xmin = fminf(bx.y, bx.w);
         const float ymax = fmaxf(bx.x, bx.z), xmax = fmaxf(bx.y, bx.w);
         const float area = (ymax - ymin) * (xmax - xmin);
@@ -434,7 +434,7 @@ __device__ inline void post_image(const NmsParams &p, int b, const PostLds &l, i
             const int cnt = l.cnt[c];
             if (cnt <= kLaneNmsMax) continue;
             const int off = l.seg[c];
-            const int kept = wave_nms<true>(sorted + off, cnt, nullptr, sbox + off, kbox, p.iou_thr, mb,
+            const int kept = wave_nms<true>(sorted + off, cnt, [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, sbox + off, kbox, p.iou_thr, mb,
                                             nullptr, nullptr, l.kpos + c * mb, off);
             if ((tid & 63) == 0) l.kept[c] = kept;
         }

@@ -64,41 +64,6 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
     }
 }
 
-// Box of row `row` (YOLOv3.py:340-348): yx = cell + 0.5 + sigmoid(t_yx),
-// hw = prior + exp(t_hw), corners scaled by the per-scale multiplier.
-template <typename Scale>
-__device__ __forceinline__ float4 decode_box(int P, Scale &sc, float ty, float tx, float th, float tw, uint32_t row)
-{
-    // row = (gy * grid_w + gx) * P + pi, taken apart without integer division: the product with
-    // floor(2^32 / d) gives the quotient or one less, one comparison settles it
-    uint32_t cell = __umulhi(row, sc.magic_p);
-    uint32_t pi = row - cell * (uint32_t)P;
-    if (pi >= (uint32_t)P) { pi -= (uint32_t)P; ++cell; }
-    uint32_t gy = __umulhi(cell, sc.magic_w);
-    uint32_t gx = cell - gy * sc.grid_w;
-    if (gx >= sc.grid_w) { gx -= sc.grid_w; ++gy; }
-    // The prior of a per-lane index: a uniform walk over the table (scalar reads of the parameter block
-    // and a select each) instead of an indexed read, which would be a vector load from memory with a
-    // full round trip in the middle of the decode.
-    float ph = sc.prior_hw[0][0], pw = sc.prior_hw[0][1];
-    for (int k = 1; k < P; ++k) {
-        const float kh = sc.prior_hw[k][0], kw = sc.prior_hw[k][1];
-        ph = pi == (uint32_t)k ? kh : ph;
-        pw = pi == (uint32_t)k ? kw : pw;
-    }
-    const float by = ((float)gy + 0.5f) + decode_sigmoid(ty);
-    const float bx = ((float)gx + 0.5f) + decode_sigmoid(tx);
-    const float bh = ph + decode_exp(th);
-    const float bw = pw + decode_exp(tw);
-    const float m = sc.mult;
-    float4 o;
-    o.x = (by - bh / 2.0f) * m;
-    o.y = (bx - bw / 2.0f) * m;
-    o.z = (by + bh / 2.0f) * m;
-    o.w = (bx + bw / 2.0f) * m;
-    return o;
-}
-
 // Appends the staged candidate keys to the image's list: one global atomic per
 // call reserves the range.  Called by every thread of the workgroup with the
 // value st.count had after the last barrier (the caller reads it before it puts
@@ -219,12 +184,11 @@ __global__ __launch_bounds__(kTileThreads) void k_stream(const StreamParams p)
             if (MODE == kModeConf) {                          // the stream is the confidence matrix itself
                 if (x >= pf) push_candidate(st, p, b, make_key(c, x, n));
             } else {
+                // the candidate's box is decoded by whoever looks at it later (row_box): the greedy walk sees a
+                // few hundred of a class's candidates, the outputs hold max_boxes of them, and a box by row for
+                // every candidate was a scattered 16-byte store and a hundred instructions each in this pass
                 const float cf = decode_sigmoid(x) * decode_sigmoid(rp[C + 4]);
-                if (cf >= p.thr) {
-                    reinterpret_cast<float4 *>(p.boxes)[(long long)b * p.N + n] =
-                        decode_box(p.P, sc, rp[C], rp[C + 1], rp[C + 2], rp[C + 3], row);
-                    push_candidate(st, p, b, make_key(c, cf, n));
-                }
+                if (cf >= p.thr) push_candidate(st, p, b, make_key(c, cf, n));
             }
         };
         auto exact_bits = [&](int w, uint32_t bits) {        // the set floats of slot w

@@ -501,6 +501,10 @@ class DetectPipeline:
         self._prev = None          # (cfg, B, workspace, outputs, device) of the batch awaiting its select stage
         self._outputs = [None, None]
         self._steady = [None, None]    # per slot: the prepared call of a batch shaped like the last one
+        # the head tensors of the batch awaiting its select stage: with a dense candidate capacity that stage
+        # decodes the boxes it looks at from them, so they stay referenced (by the Detections object returned
+        # for that batch) until the results are read
+        self._prev_heads = None
 
     def _args(self, cfg, head_ptrs, B, cap, ws, prev_ws, nbytes, outputs, dev, events):
         ev = events or (None, None)
@@ -544,6 +548,8 @@ class DetectPipeline:
             with torch.cuda.device(dev):
                 _abi.check(lib.yh_detect_pipelined(*args))
         done = Detections(*prev[3], None, stream=self.stream)
+        done.keepalive = self._prev_heads
+        self._prev_heads = list(heads)
         self._prev = mine
         self._i += 1
         return done
@@ -579,6 +585,9 @@ class DetectPipeline:
         with torch.cuda.device(dev):
             _abi.check(lib.yh_detect_pipelined(*args))
         done = Detections(*prev[3], None, stream=self.stream) if prev is not None else None
+        if done is not None:
+            done.keepalive = self._prev_heads
+        self._prev_heads = list(heads)
         self._prev = (cfg, B, ws, self._outputs[slot], dev, cap)
         if prev is not None and stream_events is None:
             self._steady[slot] = (tuple(h.shape for h in heads), dev, cap, prev[2], prev[3], args, arr,
@@ -596,7 +605,9 @@ class DetectPipeline:
         with torch.cuda.device(dev):
             _abi.check(lib.yh_detect_pipelined(*args))
         self._prev = None
-        return Detections(*outputs, None, stream=self.stream)
+        done = Detections(*outputs, None, stream=self.stream)
+        done.keepalive, self._prev_heads = self._prev_heads, None
+        return done
 
 
 class DetectLanes:
@@ -609,8 +620,10 @@ class DetectLanes:
     in submission order.  The head tensors must be complete as far as the lane's
     stream can tell: produce them on `stream_of_next()`, or pass wait_current=True
     to make the lane wait for the caller's current stream (an event record and a
-    stream wait per submit).  Keep a batch's head tensors alive until its
-    Detections have been returned: the lane's launch reads them asynchronously."""
+    stream wait per submit).  Leave a batch's head tensors unchanged until its
+    Detections have been read: the lane's launches read them asynchronously (the
+    select stage of a dense candidate set decodes boxes from them); the Detections
+    object keeps them referenced."""
 
     def __init__(self, head, score_threshold, iou_threshold, max_boxes, lanes=2, max_candidates=None,
                  want_class_candidates=False, device=None):

@@ -347,6 +347,9 @@ def main():
     ap.add_argument('--force-allreduce', action='store_true',
                     help='loss workloads with one rank: open a one-rank process group (RCCL) and all-reduce the loss '
                          'pair anyway, so that the collective runs on a single GPU')
+    ap.add_argument('--loss-prepared', action='store_true',
+                    help='loss workloads: every step issues yh_loss_prepare for its ground truth ahead of the loss call '
+                         '(same stream, inside the timed region: nothing runs here that it could hide behind)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true', help='skip the survival sweep of the detect416 line')
     ap.add_argument('--regions', type=int, default=EXTRA_REGIONS, help='timed regions after the first (percentiles)')
@@ -472,8 +475,13 @@ def main():
         if args.force_allreduce:
             extra['allreduce'] = 'forced: %d-rank %s process group' % (world, dist.get_backend())
         reuse = {}                                           # the loss outputs are written in place step after step
+        head_shapes = [tuple(h.shape) for h in sets[0]]
+        extra['ground_truth_tables'] = ('yh_loss_prepare ahead of every loss call, on the same stream' if args.loss_prepared
+                                        else 'built by the loss call')
 
         def step(i):
+            if args.loss_prepared:
+                hd.loss_prepare(head_shapes, gts[i % rotate])
             if w.get('backward'):
                 # forward + backward in one library call: d(.5 * mean loss) / d(head) for every head
                 out, _grads = hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True,
@@ -583,7 +591,23 @@ def main():
         extra['mean_loss_last_step'] = float(last.item())
         # the loss kernel alone: event pairs around back-to-back yh_loss calls without the reducer
         runs = []
-        for _ in range(5):
+        if args.loss_prepared:
+            # the preparation is spent by the call it serves, so every call gets a pair of its own with the
+            # preparation ahead of the pair (the pair's own cost, a microsecond or two, is inside the figure)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(104)]
+            for a, b in evs:
+                a.record(); b.record()
+            for i, (a, b) in enumerate(evs):
+                hd.loss_prepare(head_shapes, gts[i % rotate])
+                a.record()
+                if w.get('backward'):
+                    hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, grad_scale=0.5 / B)
+                else:
+                    reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
+                b.record()
+            torch.cuda.synchronize(dev)
+            runs = [a.elapsed_time(b) for a, b in evs[4:]]
+        for _ in range(0 if args.loss_prepared else 5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for i in range(100):
@@ -595,7 +619,9 @@ def main():
             torch.cuda.synchronize(dev)
             runs.append(a.elapsed_time(b) / 100)
         kern_runs = runs
-        timing = ('HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run), no all-reduce: ' +
+        timing = (('HIP event pairs around each of 100 prepared library calls (median; yh_loss_prepare ahead of the pair), no all-reduce: '
+                   if args.loss_prepared else
+                   'HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run), no all-reduce: ') +
                   ('two launches per call, k_loss_main (loss sums and the gradient tensor in one pass) and '
                    'k_loss_grad_pos_finalize (the assigned rows\' terms); traffic adds up both'
                    if w.get('backward') else 'one launch per call, k_loss_main, whose last workgroup combines the partial sums'))

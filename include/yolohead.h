@@ -294,6 +294,21 @@ int yh_nms_timed(int32_t batch, int64_t boxes_per_image, int32_t num_classes,
  *   data-parallel caller all-reduces (sum) that pair in place and divides:
  *   reduce_mean over the global batch without a staging buffer of its own. */
 int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pad, size_t *bytes);
+
+/* Optional first half of a loss call: everything the loss takes from the ground
+ * truth alone (YOLOv3.py:118-131, 246-257, 435-442: the rows' count, their
+ * corners and areas in every scale's grid units, the cells that hold a centre),
+ * written into `workspace` by a small launch of its own.  A training loop
+ * issues it as soon as a batch's ground truth is on the device, ahead of the
+ * convolutions, on the stream of the loss call; the NEXT yh_loss /
+ * yh_loss_forward / yh_loss_with_grad call on that workspace then skips that
+ * work in every one of its workgroups if it is a call for the same cfg,
+ * ground_truth pointer, batch and pad (and takes its usual path, same results
+ * bit for bit, if it is not).  The ground truth must not change in between.
+ * The library keeps the record of prepared workspaces (a small table, the
+ * oldest entry is dropped); the same workspace size as yh_loss. */
+int yh_loss_prepare(const yh_head_config *cfg, const float *ground_truth, int32_t batch, int32_t pad,
+                    void *workspace, size_t workspace_bytes, void *stream);
 int yh_loss(const yh_head_config *cfg, const float *const *heads, const float *ground_truth,
             int32_t batch, int32_t pad, const float *loss_scales, float ignore_threshold,
             int32_t normalize_by_num_gt, void *workspace, size_t workspace_bytes,

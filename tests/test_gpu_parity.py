@@ -752,6 +752,40 @@ def test_loss_backward_matches_oracle(gpu, version, B, G):
             assert np.array_equal(got == 0, w == 0) or np.count_nonzero((got == 0) != (w == 0)) <= 2
 
 
+def test_gradient_of_a_box_assigned_to_several_rows_is_reproducible(gpu):
+    """Five ground-truth rows of one image with the same centre and nearly the same size are assigned
+    the same box: the box's gradient is the sum of five terms, added in the order of the rows
+    whichever workgroup runs first.  The fused pass and the two-call path give the same bits, call
+    after call (atomic additions gave two or three different roundings), and the closed-form
+    float64 restatement agrees to 1e-5."""
+    case = cases.v3(size=224, C=20)
+    B, G, pad = 3, 40, 43
+    heads = case.heads(195, B, obj_mean=-1.0)
+    gt = case.gt(196, B, G, pad)
+    for j, f in ((7, 1.02), (18, 0.97), (19, 1.04), (33, 0.99)):      # rows of several workgroups (16 rows each)
+        gt[1, j, :2] = gt[1, 2, :2]
+        gt[1, j, 2:4] = gt[1, 2, 2:4] * f
+    dheads = to_dev(heads, gpu)
+    dgt = torch.from_numpy(gt).to(gpu)
+    hd = case.head_obj()
+    gw = torch.linspace(0.5, 1.5, B, device=gpu)
+    fwd = hd.loss(dheads, dgt, 1., 1., 5., 1., 0.5, True, want_mask=True)
+    first = None
+    for rep in range(6):
+        fused = hd.loss(dheads, dgt, 1., 1., 5., 1., 0.5, True, grad_per_image=gw)['grads']
+        two = hd.loss_backward(dheads, dgt, 1., 1., 5., 1., True, fwd['noobj_mask'], gw)
+        if first is None:
+            first = [g.clone() for g in fused]
+        for s in range(len(first)):
+            assert torch.equal(fused[s], first[s]) and torch.equal(two[s], first[s]), (rep, s)
+    want = O.loss_v3_grad_image([h[1] for h in heads], gt[1], case.priors, case.C)
+    for s, w in enumerate(want):
+        assert_close(first[s][1].cpu().numpy(), w * float(gw[1]), rtol=RTOL, atol=1e-7, what='grad scale %d' % s)
+    # the five rows did land on one box: fewer boxes carry a size gradient than the image has rows
+    assigned = sum(int((g[1].reshape(-1, case.C + 5)[:, case.C + 2] != 0).sum()) for g in first)
+    assert 0 < assigned <= G - 4, assigned
+
+
 def test_loss_and_grad_equals_the_autograd_path(gpu):
     """loss_and_grad (the fused library call) gives the bits torch.autograd gets from
     loss_with_grad (forward, then backward) for the same upstream factor."""
@@ -852,6 +886,81 @@ def test_loss_workspace_reused_with_new_ground_truth(gpu, c_oracle):
             per, _, _, _ = c_oracle.loss(case.oracle_cfg(c_oracle), [h.cpu().numpy() for h in heads], gts[rep],
                                          (1., 1., 5., 1.), 0.5, True)
             assert_close(got['per_image'].cpu().numpy(), per, what='per-image loss')
+
+
+def _same_bits(a, b):
+    return a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=7e30, neginf=-7e30),
+                                              torch.nan_to_num(b, nan=-7.0, posinf=7e30, neginf=-7e30))
+
+
+@pytest.mark.parametrize('version,size,B,G,pad,exact', [
+    ('v3', 416, 8, 60, 100, False), ('v3', 96, 3, 0, 3, False), ('v3', 160, 2, 5, 30, True),
+    ('v2', 416, 4, 1, 20, False), ('v3', 608, 2, 99, 100, True), ('v3', 160, 40, 7, 12, False),
+    ('v2', 480, 3, 30, 31, True)])
+def test_prepared_loss_equals_the_unprepared_call(gpu, version, size, B, G, pad, exact):
+    """yh_loss_prepare builds the ground-truth tables (pair table, cell occupancy, per-image
+    counts) ahead of the loss call; the call that finds them must give every output bit of
+    the call that builds them itself: forward with mask and IoU maxima, and the fused
+    gradient pass.  Two rows of one image share a cell (the later row wins the cell)."""
+    case = cases.v3(size=size) if version == 'v3' else cases.v2(size=size)
+    norm, thr = (True, 0.5) if version == 'v3' else (False, 0.6)
+    heads = y.synth.torch_heads(gpu, 411, B, case.grids, case.P, case.C, obj_mean=-1.0)
+    g = y.synth.make_ground_truth(412, B, G, pad, size, case.C)
+    if G > 2:
+        g[0, 1, :2] = g[0, 0, :2]
+    gt = torch.from_numpy(g).to(gpu)
+    gw = torch.linspace(0.25, 1.5, B, device=gpu)
+    plain = case.head_obj()
+    want = plain.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, want_mask=True)
+    want_g = plain.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, grad_per_image=gw)
+    hd = case.head_obj()
+    hd.loss_prepare(heads, gt)
+    got = hd.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, want_mask=True)
+    hd.loss_prepare([tuple(h.shape) for h in heads], gt)        # shapes alone are enough: the heads do not exist yet
+    got_g = hd.loss(heads, gt, 1., 0.5, 5., 2., thr, norm, want_parts=True, want_iou_max=exact, grad_per_image=gw)
+    for k in ('per_image', 'sum', 'mean', 'parts', 'noobj_mask') + (('iou_max',) if exact else ()):
+        assert _same_bits(got[k], want[k]), k
+    for k in ('per_image', 'sum', 'mean', 'parts') + (('iou_max',) if exact else ()):
+        assert _same_bits(got_g[k], want_g[k]), k
+    for s, (a, b) in enumerate(zip(got_g['grads'], want_g['grads'])):
+        assert _same_bits(a, b), s
+    if G > 0:
+        assert sum(int((a != 0).sum()) for a in got_g['grads']) > 0
+
+
+def test_a_preparation_serves_one_call_and_only_its_own_ground_truth(gpu):
+    """A preparation is consumed by the next loss call on its workspace, and only when that
+    call names the same ground-truth tensor, batch and padding: a call with OTHER ground
+    truth after a preparation, a second call after one preparation, and a preparation
+    followed by a different batch's call all give the unprepared results (a stale table
+    would give the earlier batch's mask)."""
+    case = cases.v3(size=160)
+    B, pad = 6, 24
+    heads = y.synth.torch_heads(gpu, 931, B, case.grids, case.P, case.C, obj_mean=-1.0)
+    gts = [torch.from_numpy(y.synth.make_ground_truth(950 + r, B, (3, 23, 17)[r], pad, 160, case.C)).to(gpu) for r in range(3)]
+    fresh = [case.head_obj().loss(heads, g, 1., 1., 5., 1., 0.5, True, want_mask=True) for g in gts]
+    assert not torch.equal(fresh[0]['noobj_mask'], fresh[1]['noobj_mask'])
+    hd = case.head_obj()
+    hd.loss_prepare(heads, gts[0])
+    other = hd.loss(heads, gts[1], 1., 1., 5., 1., 0.5, True, want_mask=True)      # prepared for gts[0]: not used
+    hd.loss_prepare(heads, gts[2])
+    first = hd.loss(heads, gts[2], 1., 1., 5., 1., 0.5, True, want_mask=True)      # prepared
+    again = hd.loss(heads, gts[0], 1., 1., 5., 1., 0.5, True, want_mask=True)      # the preparation is spent
+    # a training loop: prepare the next batch's tables right after this batch's loss call
+    loop = []
+    hd.loss_prepare(heads, gts[0])
+    for r in range(3):
+        loop.append(hd.loss(heads, gts[r], 1., 1., 5., 1., 0.5, True, want_mask=True))
+        if r + 1 < 3:
+            hd.loss_prepare(heads, gts[r + 1])
+    for name, got, want in (('other', other, fresh[1]), ('first', first, fresh[2]), ('again', again, fresh[0]),
+                            ('loop0', loop[0], fresh[0]), ('loop1', loop[1], fresh[1]), ('loop2', loop[2], fresh[2])):
+        assert torch.equal(got['noobj_mask'], want['noobj_mask']), name
+        assert torch.equal(got['per_image'], want['per_image']), name
+    half = [h[:3].contiguous() for h in heads]                  # another batch size: another workspace, no preparation
+    hd.loss_prepare(heads, gts[0])
+    small = hd.loss(half, gts[0][:3].contiguous(), 1., 1., 5., 1., 0.5, True, want_mask=True)
+    assert torch.equal(small['per_image'], fresh[0]['per_image'][:3])
 
 
 def test_loss_outputs_can_be_reused(gpu):

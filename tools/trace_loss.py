@@ -21,6 +21,8 @@ for i in range(10):
     if i == 9:
         torch.cuda.synchronize()
         assert lib.yh_trace_loss_read(None, 0, 1) == 0
+    if os.environ.get('PREP') == '1':
+        hd.loss_prepare(sets[i % 8], gts[i % 8])
     hd.loss(sets[i % 8], gts[i % 8], 1., 1., 5., 1., 0.5, True)
 torch.cuda.synchronize()
 tr = np.zeros((1 << 14, 8), np.uint64)

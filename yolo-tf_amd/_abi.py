@@ -84,6 +84,7 @@ SIGNATURES = {
     'yh_nms_timed': (ctypes.c_int, [_I, ctypes.c_int64, _I, _P, _P, _F, _F, _I, _I, _P, ctypes.c_size_t,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'yh_loss_workspace_bytes': (ctypes.c_int, [_CFG, _I, _I, ctypes.POINTER(ctypes.c_size_t)]),
+    'yh_loss_prepare': (ctypes.c_int, [_CFG, _P, _I, _I, _P, ctypes.c_size_t, _P]),
     'yh_loss_forward': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _F, _I, _P, ctypes.c_size_t,
                                        _P, _P, _P, _P, _P, _P]),
     'yh_loss_backward': (ctypes.c_int, [_CFG, _PP, _P, _I, _I, ctypes.POINTER(_F), _I, _P, _P, _PP, _P]),

@@ -948,12 +948,15 @@ static void plan_loss(yh::LossParams &p, const yh_head_config *cfg, int32_t batc
     // number of 128-byte lines: the scalar data cache is not coherent with the vector stores that write the
     // tables, and a line shared by two tables could be cached before its second half is written
     p.pair_cap = 8 * ((2 * ((pad + 3) / 4) + 7) / 8);
+    int occ_words = 0;
+    for (int s = 0; s < p.S; ++s) occ_words = std::max(occ_words, (p.sc[s].H * p.sc[s].W + 31) >> 5);
+    p.occ_cap = (occ_words + 31) / 32 * 32;
     p.blocks_per_img = (int32_t)blk;
     p.pos_blocks = (pad + yh::kLossPosGtPerBlock - 1) / yh::kLossPosGtPerBlock;
     if (p.pos_blocks < 1) p.pos_blocks = 1;
 }
 
-struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *pair_tab; yh::PosRecord *pos_rec; size_t bytes; };
+struct LossWs { double *pair; float *neg, *pos; int32_t *gcount; float *pair_tab; yh::PosRecord *pos_rec; uint32_t *occ_tab; int32_t *prep_flags; size_t bytes; };
 
 static LossWs carve_loss(void *base, const yh::LossParams &p)
 {
@@ -972,15 +975,57 @@ static LossWs carve_loss(void *base, const yh::LossParams &p)
     w.pos = reinterpret_cast<float *>(c + o_pos);
     w.gcount = reinterpret_cast<int32_t *>(c + o_g);
     w.pair_tab = reinterpret_cast<float *>(c + o_pp);
+    const size_t o_occ = take((size_t)p.B * p.S * p.occ_cap * 4);
+    const size_t o_flag = take((size_t)p.B * p.S * 4);
     w.pos_rec = reinterpret_cast<yh::PosRecord *>(c + o_pr);
+    w.occ_tab = reinterpret_cast<uint32_t *>(c + o_occ);
+    w.prep_flags = reinterpret_cast<int32_t *>(c + o_flag);
     w.bytes = off;
     return w;
+}
+
+// yh_loss_prepare's record: which workspace holds tables for which ground truth.  The next loss call on the
+// workspace takes the record away, and uses the tables when it is a call for that very batch.
+struct PreparedLoss { const void *ws; const float *gt; int32_t batch, pad; uint64_t cfg_hash; };
+constexpr int kPreparedLosses = 64;
+static std::mutex g_prepared_mu;
+static PreparedLoss g_prepared[kPreparedLosses];
+static unsigned g_prepared_next = 0;
+
+static uint64_t config_hash(const yh_head_config *cfg)
+{
+    uint64_t h = 1469598103934665603ull;                      // FNV-1a over the bytes of the struct
+    const unsigned char *c = reinterpret_cast<const unsigned char *>(cfg);
+    for (size_t i = 0; i < sizeof(*cfg); ++i) h = (h ^ c[i]) * 1099511628211ull;
+    return h;
+}
+
+static void record_prepared(const void *ws, const float *gt, int32_t batch, int32_t pad, uint64_t hash)
+{
+    std::lock_guard<std::mutex> lock(g_prepared_mu);
+    int at = -1;
+    for (int i = 0; i < kPreparedLosses && at < 0; ++i)
+        if (g_prepared[i].ws == ws) at = i;
+    if (at < 0) at = (int)(g_prepared_next++ % kPreparedLosses);
+    g_prepared[at] = PreparedLoss{ws, gt, batch, pad, hash};
+}
+
+static bool take_prepared(const void *ws, const float *gt, int32_t batch, int32_t pad, uint64_t hash)
+{
+    std::lock_guard<std::mutex> lock(g_prepared_mu);
+    for (int i = 0; i < kPreparedLosses; ++i)
+        if (g_prepared[i].ws == ws) {
+            const PreparedLoss r = g_prepared[i];
+            g_prepared[i] = PreparedLoss{nullptr, nullptr, 0, 0, 0};
+            return r.gt == gt && r.batch == batch && r.pad == pad && r.cfg_hash == hash;
+        }
+    return false;
 }
 
 static int check_loss_sizes(const yh_head_config *cfg, int32_t batch, int32_t pad)
 {
     if (batch < 0) return fail(YH_ERR_INVALID_ARG, "batch %d is negative", batch);
-    if (pad < 1 || pad > 2048) return fail(YH_ERR_LIMIT, "pad %d outside [1, 2048]", pad);
+    if (pad < 1 || pad > yh::kLossMaxPad) return fail(YH_ERR_LIMIT, "pad %d outside [1, %d]", pad, yh::kLossMaxPad);
     int occ_words = 0;
     for (int s = 0; s < cfg->num_scales; ++s) {
         if (!(cfg->gt_rate[s] > 0.0f)) return fail(YH_ERR_INVALID_ARG, "gt_rate[%d] must be positive", s);
@@ -1049,6 +1094,8 @@ static int loss_forward(const yh_head_config *cfg, const float *const *heads, co
     p.gt = ground_truth;
     p.neg_partial = w.neg; p.pos_partial = w.pos; p.gcount = w.gcount; p.reduce_pair = w.pair;
     p.pair_tab = w.pair_tab;
+    p.occ_tab = w.occ_tab; p.prep_flags = w.prep_flags;
+    p.prepared = take_prepared(workspace, ground_truth, batch, pad, config_hash(cfg)) ? 1 : 0;
     p.pos_rec = grad_per_image ? w.pos_rec : nullptr;
     p.cu_slots = compute_units();
     // The last workgroup of the main launch finalizes while the launch is small enough for the tickets
@@ -1061,6 +1108,29 @@ static int loss_forward(const yh_head_config *cfg, const float *const *heads, co
     p.noobj_mask = noobj_mask;
     const hipError_t e = yh::launch_loss(p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "loss launch");
+    return YH_OK;
+}
+
+int yh_loss_prepare(const yh_head_config *cfg, const float *ground_truth, int32_t batch, int32_t pad,
+                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_config(cfg);
+    if (rc != YH_OK) return rc;
+    if ((rc = check_loss_sizes(cfg, batch, pad)) != YH_OK) return rc;
+    if (batch == 0) return YH_OK;
+    if (!ground_truth || !workspace) return fail(YH_ERR_INVALID_ARG, "null ground_truth or workspace");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail(YH_ERR_ALIGN, "workspace is not 256-byte aligned");
+    yh::LossParams p;
+    plan_loss(p, cfg, batch, pad);
+    const LossWs w = carve_loss(workspace, p);
+    if (workspace_bytes < w.bytes)
+        return fail(YH_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, w.bytes);
+    if ((rc = ensure_device()) != YH_OK) return rc;
+    p.gt = ground_truth;
+    p.gcount = w.gcount; p.pair_tab = w.pair_tab; p.occ_tab = w.occ_tab; p.prep_flags = w.prep_flags;
+    const hipError_t e = yh::launch_loss_prepare(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "loss prepare launch");
+    record_prepared(workspace, ground_truth, batch, pad, config_hash(cfg));
     return YH_OK;
 }
 

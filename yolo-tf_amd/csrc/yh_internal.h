@@ -316,18 +316,24 @@ struct LossParams {
     float *pair_tab;              // [B][S][pair_cap][12]: ground-truth corners and areas in grid units, two rows side by side:
                                   //   written and read back by the negative-branch workgroups of the main launch
     int32_t pair_cap;             // pairs per (image, scale) in pair_tab: a multiple of 8 (whole 128-byte lines), >= ceil(pad / 2)
+    uint32_t *occ_tab;            // [B][S][occ_cap]: cell-occupancy bitmaps written by yh_loss_prepare
+    int32_t *prep_flags;          // [B][S]: 1 when every operand of the table is within the fast path's bounds
+    int32_t occ_cap;              // words per bitmap in occ_tab: a multiple of 32 (whole 128-byte lines)
+    int32_t prepared;             // the launch starts from what yh_loss_prepare left in the workspace
     int32_t ticket_slot;          // the launch's cell of the library's ticket array; -1: a launch of its own finalizes
     int32_t cu_slots;             // compute units of the device (0: keep the launch order of the negative-branch blocks)
     LossScale sc[YH_MAX_SCALES];
 };
 
 hipError_t launch_loss(const LossParams &p, hipStream_t st);
+hipError_t launch_loss_prepare(const LossParams &p, hipStream_t st);
 size_t loss_lds_bytes(int pad, int occ_words);      // dynamic LDS of the loss kernel: raw GT rows + occupancy bitmap
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t st);
 
 constexpr int kLossNegThreads = 256;
 constexpr int kLossBoxes = 2;            // box rows per lane of the negative branch
 constexpr int kLossNegRows = kLossNegThreads * kLossBoxes;   // box rows per workgroup
+constexpr int kLossMaxPad = 2048;       // ground-truth rows (with padding) of an image: what a workgroup's tables in LDS hold
 constexpr int kLossPosGtPerBlock = 16;  // ground-truth rows per workgroup of the positive branch
 
 }  // namespace yh

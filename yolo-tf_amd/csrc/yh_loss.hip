@@ -201,38 +201,27 @@ __device__ __forceinline__ float vmax_s(float a, float b)
     return r;
 }
 
-template <bool EXACT_MAX, bool GRAD>
-__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw, float *s_val, int *s_idx)
+// The ground-truth tables of one (image, scale), built by a whole workgroup: the raw rows staged in s_gt, the
+// corners-and-areas table written to p.pair_tab (YOLOv3.py:246-257 operand order, two rows side by side, padded
+// with copies of the last row up to a multiple of four rows: a maximum over the rows does not notice a repeated
+// row), the cell-occupancy bitmap in s_occ (YOLOv3.py:123-131).  Returns the row count; *in_bounds: this
+// thread's rows have every corner and area below 2^40 in magnitude (the caller combines the threads' flags
+// behind a barrier, which also completes s_occ).
+__device__ __forceinline__ int gt_tables(const LossParams &p, int b, int s, float *s_gt, uint32_t *s_occ, float *s_val, int *s_idx,
+                                         int *in_bounds_out)
 {
-    unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
-    (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
-    unsigned slow_turns = 0;                                    // measurement build: turns that took the exact path
-    (void)slow_turns;
-    YH_LT(lt0);
     const int tid = threadIdx.x;
-    const int b = block / p.blocks_per_img;
-    const uint32_t r = block - (uint32_t)b * p.blocks_per_img;
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < YH_MAX_SCALES; ++i)
-        if (i < p.S && r >= p.sc[i].blk_begin) s = i;
     const LossScale &sc = p.sc[s];
-    const int C = p.C, K = p.K, P = p.P, W = sc.W;
-    const int H = sc.H;
+    const int W = sc.W, H = sc.H;
     const float *gt = p.gt + (long long)b * p.pad * 5;
-    float *s_gt = reinterpret_cast<float *>(s_raw);                         // [pad][5]: the raw rows
-    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
-
     const int occ_words = (H * W + 31) >> 5;
     for (int i = tid; i < occ_words; i += kLossNegThreads) s_occ[i] = 0u;
     const int G = stage_gt(gt, p.pad, s_gt, s_val, s_idx, kLossNegThreads);   // its barriers cover s_occ too
-    YH_LT(lt1);
     const size_t bs = (size_t)b * p.S + s;
     float *tab_w = p.pair_tab + bs * (size_t)p.pair_cap * kPairStride;
-    const const_float_t *tab = (const const_float_t *)tab_w;
     const float rate = sc.gt_rate;
     const int slots = ((G + 3) >> 2) << 2;
-    int in_bounds = 1;                                          // every corner and area below 2^40 in magnitude
+    int in_bounds = 1;
     for (int g = tid; g < slots; g += kLossNegThreads) {
         const float *row = s_gt + (g < G ? g : G - 1) * 5;
         const float gy = row[0] / rate, gx = row[1] / rate;
@@ -253,8 +242,50 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             atomicOr(&s_occ[cell >> 5], 1u << (cell & 31));
         }
     }
-    stores_acknowledged();                                      // the table is in the L2 the scalar loads below read from
-    const bool gt_in_bounds = __syncthreads_and(in_bounds) != 0;
+    *in_bounds_out = in_bounds;
+    return G;
+}
+
+template <bool EXACT_MAX, bool GRAD, bool PREPARED>
+__device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t block, unsigned char *s_raw, float *s_val, int *s_idx)
+{
+    unsigned long long lt0 = 0, lt1 = 0, lt2 = 0, lt3 = 0, lt4 = 0, lt5 = 0;
+    (void)lt0; (void)lt1; (void)lt2; (void)lt3; (void)lt4; (void)lt5;
+    unsigned slow_turns = 0;                                    // measurement build: turns that took the exact path
+    (void)slow_turns;
+    YH_LT(lt0);
+    const int tid = threadIdx.x;
+    const int b = block / p.blocks_per_img;
+    const uint32_t r = block - (uint32_t)b * p.blocks_per_img;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < YH_MAX_SCALES; ++i)
+        if (i < p.S && r >= p.sc[i].blk_begin) s = i;
+    const LossScale &sc = p.sc[s];
+    const int C = p.C, K = p.K, P = p.P, W = sc.W;
+    float *s_gt = reinterpret_cast<float *>(s_raw);                         // [pad][5]: the raw rows
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
+
+    int G;
+    bool gt_in_bounds;
+    uint32_t occ_word[kLossBoxes], occ_bit[kLossBoxes];         // PREPARED: the occupancy words of the lane's cells, in flight
+#pragma unroll
+    for (int i = 0; i < kLossBoxes; ++i) { occ_word[i] = 0u; occ_bit[i] = 0u; }
+    const size_t bs = (size_t)b * p.S + s;
+    const const_float_t *tab = (const const_float_t *)(p.pair_tab + bs * (size_t)p.pair_cap * kPairStride);
+    if (PREPARED) {
+        // yh_loss_prepare left the row count, the table, the bitmap and the bounds flag of (image, scale) in the
+        // workspace: two scalar loads instead of the staging above, and the lane's occupancy words are asked
+        // for further down and looked at after the loop
+        G = ((const const_int_t *)p.gcount)[b];
+        gt_in_bounds = ((const const_int_t *)p.prep_flags)[bs] != 0;
+    } else {
+        int in_bounds;
+        G = gt_tables(p, b, s, s_gt, s_occ, s_val, s_idx, &in_bounds);
+        stores_acknowledged();                                  // the table is in the L2 the scalar loads below read from
+        gt_in_bounds = __syncthreads_and(in_bounds) != 0;
+    }
+    YH_LT(lt1);
 
     // A lane owns kLossBoxes box rows of the workgroup's run, kLossNegThreads apart.  The
     // objectness logits are not needed before the IoU loop below has run, and the loop hides
@@ -322,7 +353,13 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             const uint32_t pi = row[i] - cell * (uint32_t)P;
             const uint32_t cy = sc.magic_w ? __umulhi(cell, sc.magic_w) : cell / (uint32_t)W;
             const uint32_t cx = cell - cy * (uint32_t)W;
-            live[i] = !((s_occ[cell >> 5] >> (cell & 31)) & 1u);
+            if (PREPARED) {
+                occ_word[i] = p.occ_tab[bs * (size_t)p.occ_cap + (cell >> 5)];
+                occ_bit[i] = cell & 31u;
+                live[i] = EXACT_MAX ? !((occ_word[i] >> occ_bit[i]) & 1u) : true;   // otherwise settled behind the loop (resolve_live)
+            } else {
+                live[i] = !((s_occ[cell >> 5] >> (cell & 31)) & 1u);
+            }
             const float ay = (float)cy + 0.5f, ax = (float)cx + 0.5f;
             // uniform walk over the priors: scalar reads of the parameter block and selects.  (Written as
             // plain selects of loads, the compiler turns the walk into one load at a per-lane address: a
@@ -376,6 +413,14 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
             turn_wait(xa);
         }
         return any_nan ? __builtin_nanf("") : mx;
+    };
+    // PREPARED: the occupancy words were asked for above; whether a box lies in a cell with a ground-truth centre is
+    // only needed where the box is counted, behind the loop, so nobody waits for them before it
+    auto resolve_live = [&]() {
+        if (PREPARED && !EXACT_MAX) {
+#pragma unroll
+            for (int i = 0; i < kLossBoxes; ++i) live[i] = in_range[i] && !((occ_word[i] >> occ_bit[i]) & 1u);
+        }
     };
     if (EXACT_MAX) {
 #pragma unroll
@@ -471,9 +516,11 @@ __device__ __forceinline__ void loss_neg_block(const LossParams &p, uint32_t blo
                 }
                 turn_wait(ta);
             }
+            resolve_live();
 #pragma unroll
             for (int i = 0; i < kLossBoxes; ++i) counted[i] = live[i] && !(e_max[i] > 0.0f || masked_exact[i]);
         } else {
+            resolve_live();
 #pragma unroll
             for (int i = 0; i < kLossBoxes; ++i) {
                 if (live[i]) {
@@ -702,6 +749,7 @@ __device__ __forceinline__ int pos_from_records(const LossParams &p, int b, int 
 // of (row, channel) items spread over the workgroup's lanes, so that the cross-entropy code
 // runs on full wavefronts (a wavefront per row ran it twice on 85 of 128 lanes, after every
 // lane had repeated the row's assignment).
+template <bool PREPARED>
 __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t block, float *s_val, int *s_idx,
                                                float (*s_part)[3], PosLds &l)
 {
@@ -709,8 +757,13 @@ __device__ __forceinline__ void loss_pos_block(const LossParams &p, uint32_t blo
     const int b = (int)(block / (uint32_t)p.pos_blocks);
     const int blk = (int)block - b * p.pos_blocks;
     const float *gt = p.gt + (long long)b * p.pad * 5;
-    const int G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
-    if (blk == 0 && tid == 0) publish(&p.gcount[b], G);
+    int G;
+    if (PREPARED) {
+        G = ((const const_int_t *)p.gcount)[b];                // yh_loss_prepare counted the rows
+    } else {
+        G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+        if (blk == 0 && tid == 0) publish(&p.gcount[b], G);
+    }
     const int n = pos_assign(p, b, blk, G, l, false);
     const int C = p.C, K = p.K;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;   // item -> row by multiply-high (items < 2^17)
@@ -834,7 +887,7 @@ __device__ __forceinline__ uint32_t cu_major_block(uint32_t q, uint32_t q0, uint
 // branch (few, each a chain of dependent memory round trips: started first, they run
 // beside the compute-bound negative branch instead of after it).
 static_assert(kPosThreads == kLossNegThreads, "both branches share one launch");
-template <bool EXACT_MAX, bool GRAD>
+template <bool EXACT_MAX, bool GRAD, bool PREPARED>
 __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams p)
 {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -848,8 +901,8 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
 #ifdef YH_ROWS_TRACE
     const unsigned long long pt0 = wall_clock64();
 #endif
-    if (blockIdx.x < npos) loss_pos_block(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
-    else loss_neg_block<EXACT_MAX, GRAD>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_raw, s_val, s_idx);
+    if (blockIdx.x < npos) loss_pos_block<PREPARED>(p, blockIdx.x, s_val, s_idx, s_part, s_pos);
+    else loss_neg_block<EXACT_MAX, GRAD, PREPARED>(p, cu_major_block(blockIdx.x, npos, gridDim.x, (uint32_t)p.cu_slots), s_raw, s_val, s_idx);
 #ifdef YH_ROWS_TRACE
     if (blockIdx.x < npos && threadIdx.x == 0) {                // positive branch: start, end, place, marker 2
         const size_t at = (size_t)(gridDim.x - npos) * (kLossNegThreads / 64) + blockIdx.x;
@@ -875,6 +928,31 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_main(const LossParams 
             loss_finalize<kLossNegThreads>(p, s_sum);
             if (threadIdx.x == 0) publish(&g_loss_tickets[p.ticket_slot], 0u);
         }
+    }
+}
+
+// yh_loss_prepare: everything the loss needs from the ground truth alone, once per (image, scale) instead of once
+// per workgroup of the main launch: the row count, the corners-and-areas table, the cell-occupancy bitmap and the
+// "every operand within bounds" flag.  A training loop issues it as soon as a batch's ground truth is on the
+// device, ahead of the convolutions; the main launch that follows then starts its IoU loop after two scalar loads.
+__global__ __launch_bounds__(kLossNegThreads) void k_loss_prepare(const LossParams p)
+{
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ float s_val[kLossNegThreads / 64];
+    __shared__ int s_idx[kLossNegThreads / 64];
+    const int tid = threadIdx.x;
+    const int b = (int)(blockIdx.x / (uint32_t)p.S), s = (int)(blockIdx.x - (uint32_t)b * (uint32_t)p.S);
+    float *s_gt = reinterpret_cast<float *>(s_raw);
+    uint32_t *s_occ = reinterpret_cast<uint32_t *>(s_gt + (size_t)p.pad * 5);
+    int in_bounds;
+    const int G = gt_tables(p, b, s, s_gt, s_occ, s_val, s_idx, &in_bounds);
+    const bool ok = __syncthreads_and(in_bounds) != 0;         // the barrier completes s_occ
+    const size_t bs = (size_t)b * p.S + s;
+    const int occ_words = (p.sc[s].H * p.sc[s].W + 31) >> 5;
+    for (int i = tid; i < p.occ_cap; i += kLossNegThreads) p.occ_tab[bs * (size_t)p.occ_cap + i] = i < occ_words ? s_occ[i] : 0u;
+    if (tid == 0) {
+        p.prep_flags[bs] = ok ? 1 : 0;
+        if (s == 0) p.gcount[b] = G;
     }
 }
 
@@ -955,36 +1033,91 @@ __global__ __launch_bounds__(kLossNegThreads) void k_loss_grad_fill(const LossPa
     }
 }
 
-// Adds the assigned rows' terms (atomically: several GT rows may share a box).  Runs after
-// k_loss_grad_fill on the same stream.  Same two phases as the forward's positive branch.
-__device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t block, float *s_val, int *s_idx, PosLds &l)
+// What the gradient launch keeps per image to find the ground-truth rows that share a box.
+constexpr unsigned long long kNoBox = ~0ull;
+struct PosShare {
+    unsigned long long key[kLossMaxPad];       // (scale, first float of the assigned row) of every row of the image; kNoBox: no term
+    uint32_t flag[kLossPosGtPerBlock];         // of the workgroup's own rows: bit 0 shares its box, bit 1 is not the first of them
+};
+
+__device__ __forceinline__ unsigned long long box_key(int s, long long at)
+{
+    return ((unsigned long long)s << 56) | (unsigned long long)at;
+}
+
+// Adds the assigned rows' terms.  Runs after the gradient fill on the same stream.  Same two phases
+// as the forward's positive branch.  Several ground-truth rows may be assigned one box (same cell,
+// same prior): their terms are added up in the order of the rows by the lanes of the FIRST of them
+// and stored once, so the result does not depend on which workgroup comes first (atomic additions
+// of three or more terms would).  A box is assigned to one row in all but a few cases: those take
+// one addition per channel as before.
+__device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t block, float *s_val, int *s_idx, PosLds &l, PosShare &sh)
 {
     const int tid = threadIdx.x;
     const int b = (int)(block / (uint32_t)p.pos_blocks);
     const int blk = (int)block - b * p.pos_blocks;
+    const int g0 = blk * kLossPosGtPerBlock;
     const float *gt = p.gt + (long long)b * p.pad * 5;
     int G, n;
+    if (tid < kLossPosGtPerBlock) sh.flag[tid] = 0u;
     if (p.pos_rec) {                                           // behind a forward pass of the same call
         G = p.gcount[b];
+        for (int g = tid; g < G; g += kPosThreads) {
+            const PosRecord *rec = &p.pos_rec[(long long)b * p.pos_blocks * kLossPosGtPerBlock + g];
+            const long long at = rec->at;
+            sh.key[g] = at >= 0 ? box_key(rec->s, at) : kNoBox;
+        }
         n = pos_from_records(p, b, blk, l);
     } else {
         G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+        for (int g = tid; g < G; g += kPosThreads) {
+            const GtAssign a = assign_gt(p, gt + (long long)g * 5);
+            long long rows_img = 0;
+#pragma unroll
+            for (int s = 0; s < YH_MAX_SCALES; ++s)
+                if (s < p.S && s == a.s) rows_img = p.sc[s].rows_img;
+            sh.key[g] = a.inside ? box_key(a.s, ((long long)b * rows_img + a.row) * p.K) : kNoBox;
+        }
         n = pos_assign(p, b, blk, G, l, true);
     }
+    // (both branches end with a barrier: the keys and the cleared flags are visible)
+    for (int g = tid; g < G; g += kPosThreads) {
+        const unsigned long long key = sh.key[g];
+        if (key == kNoBox) continue;
+        for (int gl = 0; gl < kLossPosGtPerBlock; ++gl) {
+            const int mine = g0 + gl;
+            if (mine < G && mine != g && sh.key[mine] == key) atomicOr(&sh.flag[gl], g < mine ? 3u : 1u);
+        }
+    }
+    __syncthreads();
     const int C = p.C, K = p.K;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;
     float w = p.grad_w[b];
     if (p.normalize) w = w / (float)G;
+    auto term = [&](float v, int k, int label, float fy, float fx, float lh, float lw) {
+        const float z = k < C ? (k == label ? 1.0f : 0.0f) : (k == C ? fy : (k == C + 1 ? fx : 1.0f));
+        const float tgt = k == C + 2 ? lh : lw;
+        const float diff = (k == C + 2 || k == C + 3) ? v - tgt : sigmoidf(v) - z;
+        const float d = (k < C ? p.w_class : (k < C + 4 ? p.w_coord : p.w_obj)) * diff;
+        return d * w;
+    };
     for (int it = tid; it < n * K; it += kPosThreads) {
         const int gl = (int)__umulhi((uint32_t)it, magic), k = it - gl * K;
         const float *rowp = l.rowp[gl];
         if (!rowp) continue;
+        const uint32_t flag = sh.flag[gl];
+        if (flag & 2u) continue;                                // an earlier row of the same box adds this row's term
         const float v = rowp[k];
-        const float z = k < C ? (k == l.label[gl] ? 1.0f : 0.0f) : (k == C ? l.fy[gl] : (k == C + 1 ? l.fx[gl] : 1.0f));
-        const float tgt = k == C + 2 ? l.lh[gl] : l.lw[gl];
-        const float diff = (k == C + 2 || k == C + 3) ? v - tgt : sigmoidf(v) - z;
-        const float d = (k < C ? p.w_class : (k < C + 4 ? p.w_coord : p.w_obj)) * diff;
-        atomicAdd(&l.growp[gl][k], d * w);
+        float sum = term(v, k, l.label[gl], l.fy[gl], l.fx[gl], l.lh[gl], l.lw[gl]);
+        if (flag & 1u) {                                        // the later rows of this box, in their order
+            const unsigned long long key = sh.key[g0 + gl];
+            for (int g = g0 + gl + 1; g < G; ++g) {
+                if (sh.key[g] != key) continue;
+                const GtAssign a = assign_gt(p, gt + (long long)g * 5);      // the targets as pos_assign computes them
+                sum += term(v, k, a.label, a.gy - floorf(a.gy), a.gx - floorf(a.gx), logf(a.gh / a.prior_h), logf(a.gw / a.prior_w));
+            }
+        }
+        l.growp[gl][k] += sum;                                  // the fill left zero here (no no-object term in a cell with a centre)
     }
 }
 
@@ -993,7 +1126,8 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos(const LossParams 
     __shared__ float s_val[kPosThreads / 64];
     __shared__ int s_idx[kPosThreads / 64];
     __shared__ PosLds s_pos;
-    loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos);
+    __shared__ PosShare s_share;
+    loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos, s_share);
 }
 
 // After the fused forward + gradient-fill pass: the assigned rows' terms, and in one more
@@ -1004,8 +1138,9 @@ __global__ __launch_bounds__(kPosThreads) void k_loss_grad_pos_finalize(const Lo
     __shared__ int s_idx[kPosThreads / 64];
     __shared__ double s_sum[kFinalizeClasses];
     __shared__ PosLds s_pos;
+    __shared__ PosShare s_share;
     if (blockIdx.x + 1u == gridDim.x) loss_finalize<kPosThreads>(p, s_sum);
-    else loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos);
+    else loss_grad_pos(p, blockIdx.x, s_val, s_idx, s_pos, s_share);
 }
 
 hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
@@ -1015,6 +1150,21 @@ hipError_t launch_loss_backward(const LossParams &p, hipStream_t stm)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_loss_grad_pos, dim3((uint32_t)p.B * (uint32_t)p.pos_blocks), dim3(kPosThreads), 0, stm, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_prepare(const LossParams &p, hipStream_t stm)
+{
+    if (p.B == 0) return hipSuccess;
+    int occ_words = 0;
+    for (int s = 0; s < p.S; ++s) {
+        const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
+        if (w > occ_words) occ_words = w;
+    }
+    const size_t lds = loss_lds_bytes(p.pad, occ_words);
+    const hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(k_loss_prepare), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss_prepare, dim3((uint32_t)p.B * (uint32_t)p.S), dim3(kLossNegThreads), lds, stm, p);
     return hipGetLastError();
 }
 
@@ -1031,11 +1181,16 @@ hipError_t launch_loss(const LossParams &p, hipStream_t stm)
         const int w = (p.sc[s].H * p.sc[s].W + 31) >> 5;
         if (w > occ_words) occ_words = w;
     }
-    const size_t lds = loss_lds_bytes(p.pad, occ_words);
+    const size_t lds = p.prepared ? 0 : loss_lds_bytes(p.pad, occ_words);   // a prepared launch stages nothing
     const dim3 grid((uint32_t)p.B * (uint32_t)(p.pos_blocks + p.blocks_per_img));
     const bool grad = p.grad_w != nullptr;                     // forward and gradient in one pass over the rows
-    void (*kernel)(const LossParams) = p.iou_max ? (grad ? k_loss_main<true, true> : k_loss_main<true, false>)
-                                                 : (grad ? k_loss_main<false, true> : k_loss_main<false, false>);
+    void (*kernel)(const LossParams);
+    if (p.prepared)
+        kernel = p.iou_max ? (grad ? k_loss_main<true, true, true> : k_loss_main<true, false, true>)
+                           : (grad ? k_loss_main<false, true, true> : k_loss_main<false, false, true>);
+    else
+        kernel = p.iou_max ? (grad ? k_loss_main<true, true, false> : k_loss_main<true, false, false>)
+                           : (grad ? k_loss_main<false, true, false> : k_loss_main<false, false, false>);
     hipError_t e = raise_lds_limit(reinterpret_cast<const void *>(kernel), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, grid, dim3(kLossNegThreads), lds, stm, p);

@@ -138,6 +138,12 @@ class DetectionHead:
             out.append(h.contiguous())
         return out
 
+    def config_for_shapes(self, shapes):
+        class _Shape:
+            def __init__(self, shape):
+                self.shape = shape
+        return self.config_for([_Shape(s) for s in shapes])
+
     def config_for(self, heads):
         grids = tuple((int(h.shape[1]), int(h.shape[2])) for h in heads)
         cfg = self._configs.get(grids)
@@ -330,6 +336,30 @@ class DetectionHead:
         return Detections(count, scores, oboxes, cls, idx, cc, status, rerun)
 
     # --------------------------------------------------------------- loss
+    def loss_prepare(self, head_shapes, ground_truth):
+        """yh_loss_prepare: the ground-truth half of the next loss() / loss_and_grad() call for heads of these
+        shapes ([B, H, W, P*(C+5)] per scale; tensors are accepted too) and this very ground_truth tensor
+        ([B, pad, 5] float32, contiguous, on the device), issued on the current stream.  Optional: a training
+        loop calls it as soon as the batch's ground truth is on the device, before the convolutions run."""
+        lib = _abi.load()
+        shapes = [tuple(h.shape) if isinstance(h, torch.Tensor) else tuple(int(v) for v in h) for h in head_shapes]
+        gt = ground_truth
+        if not (isinstance(gt, torch.Tensor) and gt.dtype is torch.float32 and gt.is_contiguous() and gt.is_cuda):
+            raise ValueError('loss_prepare takes the float32, contiguous device tensor that loss() will be given')
+        B = shapes[0][0]
+        if gt.dim() != 3 or gt.shape[0] != B or gt.shape[2] != 5:
+            raise ValueError('ground_truth must be [B, pad, 5]')
+        cfg = self.config_for_shapes(shapes)
+        dev, pad = gt.device, int(gt.shape[1])
+        wkey = ('loss', tuple(shapes), pad)
+        ws = self._ws.get(wkey)
+        if ws is None or ws.device != dev:
+            nbytes = ctypes.c_size_t(0)
+            _abi.check(lib.yh_loss_workspace_bytes(ctypes.byref(cfg), B, pad, ctypes.byref(nbytes)))
+            ws = self._workspace(wkey, nbytes.value, dev)
+        with torch.cuda.device(dev):
+            _abi.check(lib.yh_loss_prepare(ctypes.byref(cfg), gt.data_ptr(), B, pad, ws.data_ptr(), ws.numel(), self._stream(dev)))
+
     def loss(self, heads, ground_truth, coord_scale, noobj_scale, obj_scale, class_scale,
              ignore_threshold, normalize_by_num_gt, want_parts=False, want_iou_max=False, want_mask=False,
              out=None, grad_per_image=None):

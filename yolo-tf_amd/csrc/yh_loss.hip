@@ -723,26 +723,6 @@ __device__ __forceinline__ int pos_assign(const LossParams &p, int b, int blk, i
     return n;
 }
 
-// Phase one of the gradient launch behind a forward pass in the same call: the records that pass left.
-__device__ __forceinline__ int pos_from_records(const LossParams &p, int b, int blk, PosLds &l)
-{
-    const int tid = threadIdx.x;
-    if (tid < kLossPosGtPerBlock) {
-        const PosRecord rec = p.pos_rec[((long long)b * p.pos_blocks + blk) * kLossPosGtPerBlock + tid];
-        const float *rowp = nullptr;
-        float *growp = nullptr;
-        if (rec.at >= 0) {
-#pragma unroll
-            for (int s = 0; s < YH_MAX_SCALES; ++s)
-                if (s < p.S && s == rec.s) { rowp = p.sc[s].head + rec.at; growp = p.sc[s].grad + rec.at; }
-        }
-        l.rowp[tid] = rowp; l.growp[tid] = growp;
-        l.fy[tid] = rec.fy; l.fx[tid] = rec.fx; l.lh[tid] = rec.lh; l.lw[tid] = rec.lw; l.label[tid] = rec.label;
-    }
-    __syncthreads();
-    return kLossPosGtPerBlock;
-}
-
 // ---------------------------------------------------------------- positive
 // B * pos_blocks workgroups; one takes kLossPosGtPerBlock ground-truth rows of one image.
 // Phase one (pos_assign): a lane per row.  Phase two: the rows' K channels as one flat list
@@ -1038,6 +1018,9 @@ constexpr unsigned long long kNoBox = ~0ull;
 struct PosShare {
     unsigned long long key[kLossMaxPad];       // (scale, first float of the assigned row) of every row of the image; kNoBox: no term
     uint32_t flag[kLossPosGtPerBlock];         // of the workgroup's own rows: bit 0 shares its box, bit 1 is not the first of them
+    uint32_t later[kLossPosGtPerBlock][kLossMaxPad / 32];   // of the workgroup's own rows: the later rows of the image with the same box, a bit each
+    uint32_t first[kLossPosGtPerBlock];        // the first of them
+    uint32_t nlater[kLossPosGtPerBlock];       // their number
 };
 
 __device__ __forceinline__ unsigned long long box_key(int s, long long at)
@@ -1058,18 +1041,38 @@ __device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t bloc
     const int blk = (int)block - b * p.pos_blocks;
     const int g0 = blk * kLossPosGtPerBlock;
     const float *gt = p.gt + (long long)b * p.pad * 5;
-    int G, n;
-    if (tid < kLossPosGtPerBlock) sh.flag[tid] = 0u;
-    if (p.pos_rec) {                                           // behind a forward pass of the same call
-        G = p.gcount[b];
+    int G, n;       // G: rows of the image that may carry a key (the count behind k_loss_grad_fill, every record slot behind a forward pass)
+    int Gn;         // the image's row count (the normalisation's divisor)
+    if (tid < kLossPosGtPerBlock) { sh.flag[tid] = 0u; sh.first[tid] = 0x7fffffffu; sh.nlater[tid] = 0u; }
+    for (int i = tid; i < kLossPosGtPerBlock * (kLossMaxPad / 32); i += kPosThreads) (&sh.later[0][0])[i] = 0u;
+    const PosRecord *recs = nullptr;
+    if (p.pos_rec) {
+        // Behind a forward pass of the same call: the records it left, one per slot of the image's positive-branch
+        // workgroups (at = -1 where the slot has no row or the row no term).  Everything this phase needs is asked
+        // for at once: one memory round trip.
+        G = p.pos_blocks * kLossPosGtPerBlock;
+        recs = p.pos_rec + (long long)b * G;
+        Gn = p.gcount[b];
         for (int g = tid; g < G; g += kPosThreads) {
-            const PosRecord *rec = &p.pos_rec[(long long)b * p.pos_blocks * kLossPosGtPerBlock + g];
-            const long long at = rec->at;
-            sh.key[g] = at >= 0 ? box_key(rec->s, at) : kNoBox;
+            const PosRecord rec = recs[g];
+            sh.key[g] = rec.at >= 0 ? box_key(rec.s, rec.at) : kNoBox;
+            const int gl = g - g0;
+            if (gl >= 0 && gl < kLossPosGtPerBlock) {
+                const float *rowp = nullptr;
+                float *growp = nullptr;
+                if (rec.at >= 0) {
+#pragma unroll
+                    for (int s = 0; s < YH_MAX_SCALES; ++s)
+                        if (s < p.S && s == rec.s) { rowp = p.sc[s].head + rec.at; growp = p.sc[s].grad + rec.at; }
+                }
+                l.rowp[gl] = rowp; l.growp[gl] = growp;
+                l.fy[gl] = rec.fy; l.fx[gl] = rec.fx; l.lh[gl] = rec.lh; l.lw[gl] = rec.lw; l.label[gl] = rec.label;
+            }
         }
-        n = pos_from_records(p, b, blk, l);
+        __syncthreads();
+        n = kLossPosGtPerBlock;
     } else {
-        G = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
+        G = Gn = block_gt_count(gt, p.pad, s_val, s_idx, kPosThreads);
         for (int g = tid; g < G; g += kPosThreads) {
             const GtAssign a = assign_gt(p, gt + (long long)g * 5);
             long long rows_img = 0;
@@ -1086,14 +1089,17 @@ __device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t bloc
         if (key == kNoBox) continue;
         for (int gl = 0; gl < kLossPosGtPerBlock; ++gl) {
             const int mine = g0 + gl;
-            if (mine < G && mine != g && sh.key[mine] == key) atomicOr(&sh.flag[gl], g < mine ? 3u : 1u);
+            if (mine < G && mine != g && sh.key[mine] == key) {
+                atomicOr(&sh.flag[gl], g < mine ? 3u : 1u);
+                if (g > mine) { atomicOr(&sh.later[gl][g >> 5], 1u << (g & 31)); atomicMin(&sh.first[gl], (uint32_t)g); atomicAdd(&sh.nlater[gl], 1u); }
+            }
         }
     }
     __syncthreads();
     const int C = p.C, K = p.K;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;
     float w = p.grad_w[b];
-    if (p.normalize) w = w / (float)G;
+    if (p.normalize) w = w / (float)Gn;
     auto term = [&](float v, int k, int label, float fy, float fx, float lh, float lw) {
         const float z = k < C ? (k == label ? 1.0f : 0.0f) : (k == C ? fy : (k == C + 1 ? fx : 1.0f));
         const float tgt = k == C + 2 ? lh : lw;
@@ -1101,23 +1107,69 @@ __device__ __forceinline__ void loss_grad_pos(const LossParams &p, uint32_t bloc
         const float d = (k < C ? p.w_class : (k < C + 4 ? p.w_coord : p.w_obj)) * diff;
         return d * w;
     };
+    // Behind the fused forward pass the word added to is known to be zero: that pass counts no box of a cell that
+    // holds a ground-truth centre, and an assigned box lies in such a cell; nothing is read back then.  Behind
+    // k_loss_grad_fill the caller's mask decides what the word holds.
+    const bool after_forward = p.pos_rec != nullptr;
+    // kGradBatch items per lane at a time: the head values, the gradient words where they are read and, for the
+    // first row of a box shared by two, the record of the other row are asked for together (one memory round trip
+    // per batch; item after item, every item's loads wait behind the store of the item before, which the compiler
+    // may not move them across).  A row that is not the first of its box has nothing to do.
+    constexpr int kGradBatch = 6;
+    bool leftovers = false;                                     // a box shared by three or more rows, or shared and no records
+    for (int it0 = tid; it0 < n * K; it0 += kPosThreads * kGradBatch) {
+        int gls[kGradBatch], ks[kGradBatch];
+        bool on[kGradBatch], two[kGradBatch];
+        float v[kGradBatch], old[kGradBatch];
+        PosRecord nrec[kGradBatch];
+#pragma unroll
+        for (int j = 0; j < kGradBatch; ++j) {
+            const int it = it0 + j * kPosThreads;
+            on[j] = it < n * K;
+            gls[j] = on[j] ? (int)__umulhi((uint32_t)it, magic) : 0;
+            ks[j] = it - gls[j] * K;
+            const uint32_t flag = sh.flag[gls[j]];
+            on[j] = on[j] && l.rowp[gls[j]] != nullptr && !(flag & 2u);
+            two[j] = on[j] && (flag & 1u);
+            if (two[j] && !(recs && sh.nlater[gls[j]] == 1u)) { on[j] = two[j] = false; leftovers = true; }
+            v[j] = on[j] ? l.rowp[gls[j]][ks[j]] : 0.0f;
+            old[j] = (on[j] && !after_forward) ? l.growp[gls[j]][ks[j]] : 0.0f;
+            nrec[j] = PosRecord{-1, 0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (two[j]) nrec[j] = recs[sh.first[gls[j]]];
+        }
+#pragma unroll
+        for (int j = 0; j < kGradBatch; ++j) {
+            if (!on[j]) continue;
+            const int gl = gls[j], k = ks[j];
+            float sum = old[j] + term(v[j], k, l.label[gl], l.fy[gl], l.fx[gl], l.lh[gl], l.lw[gl]);
+            if (two[j]) sum += term(v[j], k, nrec[j].label, nrec[j].fy, nrec[j].fx, nrec[j].lh, nrec[j].lw);
+            l.growp[gl][k] = sum;
+        }
+    }
+    // What is left: the later rows of the box in their order (the set bits of later[], lowest first), with the targets
+    // of the rows' records, or computed again as pos_assign computes them.
+    if (!__syncthreads_or(leftovers)) return;
     for (int it = tid; it < n * K; it += kPosThreads) {
         const int gl = (int)__umulhi((uint32_t)it, magic), k = it - gl * K;
         const float *rowp = l.rowp[gl];
-        if (!rowp) continue;
-        const uint32_t flag = sh.flag[gl];
-        if (flag & 2u) continue;                                // an earlier row of the same box adds this row's term
+        if (!rowp || sh.flag[gl] != 1u || (recs && sh.nlater[gl] == 1u)) continue;
         const float v = rowp[k];
-        float sum = term(v, k, l.label[gl], l.fy[gl], l.fx[gl], l.lh[gl], l.lw[gl]);
-        if (flag & 1u) {                                        // the later rows of this box, in their order
-            const unsigned long long key = sh.key[g0 + gl];
-            for (int g = g0 + gl + 1; g < G; ++g) {
-                if (sh.key[g] != key) continue;
-                const GtAssign a = assign_gt(p, gt + (long long)g * 5);      // the targets as pos_assign computes them
-                sum += term(v, k, a.label, a.gy - floorf(a.gy), a.gx - floorf(a.gx), logf(a.gh / a.prior_h), logf(a.gw / a.prior_w));
+        float sum = (after_forward ? 0.0f : l.growp[gl][k]) + term(v, k, l.label[gl], l.fy[gl], l.fx[gl], l.lh[gl], l.lw[gl]);
+        for (int w = (g0 + gl) >> 5; w * 32 < G; ++w) {
+            uint32_t bits = sh.later[gl][w];                    // only rows after this one were entered
+            while (bits != 0u) {
+                const int g = w * 32 + __builtin_ctz(bits);
+                bits &= bits - 1u;
+                if (recs) {
+                    const PosRecord rec = recs[g];
+                    sum += term(v, k, rec.label, rec.fy, rec.fx, rec.lh, rec.lw);
+                } else {
+                    const GtAssign a = assign_gt(p, gt + (long long)g * 5);
+                    sum += term(v, k, a.label, a.gy - floorf(a.gy), a.gx - floorf(a.gx), logf(a.gh / a.prior_h), logf(a.gw / a.prior_w));
+                }
             }
         }
-        l.growp[gl][k] += sum;                                  // the fill left zero here (no no-object term in a cell with a centre)
+        l.growp[gl][k] = sum;
     }
 }
 

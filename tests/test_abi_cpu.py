@@ -119,3 +119,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')) or f == 'Makefile':
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in text.lower(), '%s mentions the oracle' % os.path.join(dirpath, f)
+
+
+def test_inflight_checker_sees_a_register_touched_between_issue_and_wait():
+    """tools/check_inflight.py (run by the build on the loss kernels' generated code): a copy of a register
+    whose scalar load is still in flight is reported, on the straight path and on a path through a branch;
+    clean code is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_inflight', os.path.join(ROOT, 'tools', 'check_inflight.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    def body(between):
+        return ['\t;;#ASMSTART', '\ts_load_dwordx8 s[36:43], s[4:5], 0x0', '\ts_load_dwordx2 s[44:45], s[4:5], 0x20', '\t;;#ASMEND'] + between + [
+            '\t;;#ASMSTART', '\ts_waitcnt lgkmcnt(0)', '\t;;#ASMEND', '\tv_min_f32 v1, s36, v2', '\ts_endpgm']
+    n, errors = mod.check('clean', body(['\tv_add_f32 v0, v1, v2', '\ts_mov_b32 s50, s51']))
+    assert n == 1 and errors == []
+    n, errors = mod.check('spill', body(['\tv_writelane_b32 v40, s44, 3']))
+    assert n == 1 and len(errors) == 1 and 's[44]' in errors[0].replace('s[44]', 's[44]')
+    n, errors = mod.check('branch', body(['\ts_cbranch_scc1 .LBB0_2', '\tv_add_f32 v0, v1, v2', '\ts_branch .LBB0_3', '.LBB0_2:',
+                                          '\ts_mov_b64 s[60:61], s[38:39]', '.LBB0_3:']))
+    assert len(errors) == 1 and 's_mov_b64' in errors[0]

@@ -196,8 +196,9 @@ __host__ __device__ inline int prefix_room(int max_boxes)
 __host__ __device__ inline size_t kept_boxes_bytes(int max_boxes) { return ((size_t)max_boxes * 5 * sizeof(float) + 15) & ~(size_t)15; }
 
 // Bins of s_hist -> the first bin at which the running count reaches `target`; wave 0 only.
-// Returns the bin, its inclusive running count in *cum; `before` is added to the counts.
-__device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before, int target, int *cum)
+// Returns the bin, its inclusive running count in *cum; `before` is added to the counts.  s_excl, when
+// given, receives every bin's exclusive running count (without `before`).
+__device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before, int target, int *cum, int *s_excl = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int a[4], sum = 0;
@@ -212,6 +213,7 @@ __device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before,
     int c = before + incl - sum, found = -1, at = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (s_excl) s_excl[4 * lane + k] = c - before;
         c += a[k];
         if (found < 0 && c >= target) { found = 4 * lane + k; at = c; }
     }
@@ -222,52 +224,94 @@ __device__ __forceinline__ int first_bin_reaching(const int *s_hist, int before,
     return __builtin_amdgcn_readlane(found, src);
 }
 
-// Block-wide.  s_keys[0..cnt) -> s_sel[0..n): the n smallest keys for some n in [target, room],
-// unordered; returns n, or 0 when no such prefix exists at the two levels' resolution.
+// The tables select_prefix leaves for sort_selected.  The selection is grouped by the top byte of the keys'
+// score bits, and the keys of the boundary bin d1 (in practice nearly all of them: the top byte is sign and
+// exponent, and the best scores of a segment share theirs) by the next byte.  end1 / end2: one past a group's
+// last key in the selection; count1 / count2: its size.
+struct PrefixBins {
+    int end1[kSegThreads], count1[kSegThreads];
+    int end2[kSegThreads], count2[kSegThreads];
+    int d1;
+};
+
+// Block-wide.  s_keys[0..cnt) -> s_sel[0..n): the n smallest keys for some n in [target, room], group after
+// group in key order, any order inside a group (bins has the layout); returns n, or 0 when no such prefix
+// exists at the two levels' resolution.
 __device__ inline int select_prefix(const unsigned long long *s_keys, int cnt, int target, int room,
-                                    unsigned long long *s_sel, int *s_hist, int *s_ctl)
+                                    unsigned long long *s_sel, int *s_ctl, PrefixBins &bins)
 {
     const int tid = threadIdx.x;
     constexpr int kShift1 = 44, kShift2 = 36;              // the top two bytes of the 32 score bits at [51:20]
-    s_hist[tid] = 0;                                        // kSegThreads == 256 bins
+    bins.count1[tid] = 0;                                   // kSegThreads == 256 bins
+    bins.count2[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < cnt; i += kSegThreads) atomicAdd(&s_hist[(int)(s_keys[i] >> kShift1) & 0xFF], 1);
+    for (int i = tid; i < cnt; i += kSegThreads) atomicAdd(&bins.count1[(int)(s_keys[i] >> kShift1) & 0xFF], 1);
     __syncthreads();
     if (tid < 64) {
         int cum;
-        const int d1 = first_bin_reaching(s_hist, 0, target, &cum);
-        if (tid == 0) { s_ctl[0] = d1; s_ctl[1] = cum; s_ctl[2] = cum - s_hist[d1]; s_ctl[3] = 0; }
+        const int d1 = first_bin_reaching(bins.count1, 0, target, &cum, bins.end1);    // end1: the groups' starts for now
+        if (tid == 0) { s_ctl[0] = d1; s_ctl[1] = cum; s_ctl[2] = cum - bins.count1[d1]; }
     }
     __syncthreads();
     const int d1 = s_ctl[0], cum1 = s_ctl[1], below = s_ctl[2];
-    int d2 = 255, n = cum1;
     __syncthreads();
-    if (cum1 > target + (target >> 2)) {                    // the boundary bin overshoots: split it by the next byte
-        s_hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < cnt; i += kSegThreads) {
-            const unsigned long long k = s_keys[i];
-            if (((int)(k >> kShift1) & 0xFF) == d1) atomicAdd(&s_hist[(int)(k >> kShift2) & 0xFF], 1);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            int cum;
-            const int d = first_bin_reaching(s_hist, below, target, &cum);
-            if (tid == 0) { s_ctl[0] = d; s_ctl[1] = cum; }
-        }
-        __syncthreads();
-        d2 = s_ctl[0];
-        n = s_ctl[1];
-        __syncthreads();
+    for (int i = tid; i < cnt; i += kSegThreads) {          // the boundary bin by the next byte
+        const unsigned long long k = s_keys[i];
+        if (((int)(k >> kShift1) & 0xFF) == d1) atomicAdd(&bins.count2[(int)(k >> kShift2) & 0xFF], 1);
     }
+    __syncthreads();
+    // whole when it does not overshoot (a target nobody reaches: the last bin, every key of the bin)
+    if (tid < 64) {
+        int cum;
+        const int d = first_bin_reaching(bins.count2, below, cum1 > target + (target >> 2) ? target : 0x7fffffff, &cum, bins.end2);
+        if (tid == 0) { s_ctl[0] = d; s_ctl[1] = cum; }
+    }
+    __syncthreads();
+    const int d2 = s_ctl[0], n = s_ctl[1];
     if (n > room) return 0;                                 // s_sel holds `room` keys
+    if (tid == 0) bins.d1 = d1;
+    bins.end2[tid] += below;                                // starts inside the selection
+    __syncthreads();
     for (int i = tid; i < cnt; i += kSegThreads) {
         const unsigned long long k = s_keys[i];
         const int b1 = (int)(k >> kShift1) & 0xFF, b2 = (int)(k >> kShift2) & 0xFF;
-        if (b1 < d1 || (b1 == d1 && b2 <= d2)) s_sel[atomicAdd(&s_ctl[3], 1)] = k;
+        if (b1 < d1) s_sel[atomicAdd(&bins.end1[b1], 1)] = k;
+        else if (b1 == d1 && b2 <= d2) s_sel[atomicAdd(&bins.end2[b2], 1)] = k;
     }
     __syncthreads();
     return n;
+}
+
+// Sorts the selection select_prefix left (keys are unique): a key's place is its group's start plus the number
+// of smaller keys in its group, a handful of comparisons where the ranking of the whole selection against
+// itself takes n per key.  Every thread holds its keys (n <= KPT * kSegThreads) and their places before any is
+// written.
+template <int KPT>
+__device__ __forceinline__ void sort_selected(unsigned long long *s_sel, int n, const PrefixBins &bins)
+{
+    const int tid = threadIdx.x;
+    const int d1 = bins.d1;
+    unsigned long long key[KPT];
+    int place[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = u * kSegThreads + tid;
+        key[u] = i < n ? s_sel[i] : 0ull;
+        place[u] = 0;
+        if (i < n) {
+            const int b1 = (int)(key[u] >> 44) & 0xFF, b2 = (int)(key[u] >> 36) & 0xFF;
+            const int end = b1 < d1 ? bins.end1[b1] : bins.end2[b2];
+            const int start = end - (b1 < d1 ? bins.count1[b1] : bins.count2[b2]);
+            int r = start;
+            for (int j = start; j < end; ++j) r += s_sel[j] < key[u] ? 1 : 0;
+            place[u] = r;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if (u * kSegThreads + tid < n) s_sel[place[u]] = key[u];
+    __syncthreads();
 }
 
 // Sorts keys[0..n) in place by rank (keys are unique): a thread holds KPT keys in registers, reads the whole
@@ -331,7 +375,7 @@ struct BlockNmsLds {
 
 template <typename BoxOf>
 __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf box_of, float (*kbox)[5],
-                                float thr, int max_boxes, int32_t *krow, float *kscore, BlockNmsLds &l)
+                                float thr, int max_boxes, int32_t *krow, float *kscore, BlockNmsLds &l, const float4 *cbox = nullptr)
 {
     static_assert(kSegThreads == 256, "sixteen columns of the bit matrix per wavefront");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,7 +386,7 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf b
         const unsigned long long key = valid ? keys[i] : 0ull;
         const int n = key_row(key);
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) bx = box_of(n);
+        if (valid) bx = cbox ? cbox[i] : box_of(n);
         const float ymin = fminf(bx.x, bx.z), xmin = fminf(bx.y, bx.w);
         const float ymax = fmaxf(bx.x, bx.z), xmax = fmaxf(bx.y, bx.w);
         const float area = (ymax - ymin) * (xmax - xmin);
@@ -351,8 +395,10 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf b
         for (int j = kept - 1 - wave; j >= 0; j -= kSegThreads / 64) {
             if (__ballot(alive) == 0ull) break;
             const float *kb = kbox[j];
-            if (alive && suppresses(ymin, xmin, ymax, xmax, area, kb[0], kb[1], kb[2], kb[3], kb[4], thr))
-                alive = false;
+            // the intersections of the whole wavefront first: most selected boxes touch none of the tile's candidates
+            const float inter = intersection(ymin, xmin, ymax, xmax, kb[0], kb[1], kb[2], kb[3]);
+            if (__ballot(alive && inter > 0.0f) == 0ull) continue;
+            if (alive && suppresses_at(inter, area, kb[4], thr)) alive = false;
         }
         const unsigned long long dead = __ballot(valid && !alive);
         if (lane == 0) l.dead[wave] = dead;
@@ -363,6 +409,33 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf b
         alive = (alive_mask >> lane) & 1ull;
         // inside the tile: bit j of the mask = "the earlier lane j would suppress me"; columns 16 * wave ..
         uint32_t m = 0u;
+        if (cbox) {
+            // the columns' boxes as broadcast reads of the LDS copy, eight asked for before the first is
+            // used: eight independent tests (column after column out of a lane's registers, every test waits
+            // for the scalar unit to hand the column's five values over)
+            constexpr int kCols = 8;
+#pragma unroll 1
+            for (int c0 = 0; c0 < 16; c0 += kCols) {
+                if (((alive_mask >> (16 * wave + c0)) & ((1ull << kCols) - 1ull)) == 0ull) continue;   // nobody left in these columns
+                float4 cb[kCols];
+#pragma unroll
+                for (int c = 0; c < kCols; ++c) {
+                    const int j = t + 16 * wave + c0 + c;
+                    cb[c] = j < cnt ? cbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < kCols; ++c) {
+                    const int j = 16 * wave + c0 + c;
+                    const float jy0 = fminf(cb[c].x, cb[c].z), jx0 = fminf(cb[c].y, cb[c].w);
+                    const float jy1 = fmaxf(cb[c].x, cb[c].z), jx1 = fmaxf(cb[c].y, cb[c].w);
+                    // the intersections of the whole wavefront first: most columns touch no later candidate
+                    const float inter = intersection(ymin, xmin, ymax, xmax, jy0, jx0, jy1, jx1);
+                    const bool mine = alive && lane > j && ((alive_mask >> j) & 1ull);
+                    if (__ballot(mine && inter > 0.0f) == 0ull) continue;
+                    if (mine && suppresses_at(inter, area, (jy1 - jy0) * (jx1 - jx0), thr)) m |= 1u << (c0 + c);
+                }
+            }
+        } else
         for (unsigned long long rem = alive_mask & (0xFFFFull << (16 * wave)); rem != 0ull; rem &= rem - 1ull) {
             const int j = __ffsll((long long)rem) - 1;
             const float jy0 = lane_bcast(ymin, j), jx0 = lane_bcast(xmin, j);
@@ -398,8 +471,8 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     float (*s_kbox)[5] = reinterpret_cast<float (*)[5]>(s_dyn);
     unsigned long long *s_sel = reinterpret_cast<unsigned long long *>(s_dyn + kept_boxes_bytes(p.max_boxes));
     const int sel_room = prefix_room(p.max_boxes);
-    __shared__ int s_hist[kSegThreads];
     __shared__ int s_ctl[4];
+    __shared__ PrefixBins s_bins;
     __shared__ BlockNmsLds s_walk;
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int b = seg / p.C;
@@ -452,14 +525,28 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
         // a prefix of about 240 keys sorts as 256 (the selection overshoots its target by a few keys)
         const int target = prefix_target(p.max_boxes);
         if (cnt >= 2 * target && sel_room > 0) {
-            const int n = select_prefix(s_keys, cnt, target, sel_room, s_sel, s_hist, s_ctl);
+            const int n = select_prefix(s_keys, cnt, target, sel_room, s_sel, s_ctl, s_bins);
             if (n > 0) {
-                sort_prefix(s_sel, n);
-                const int kept = block_walk(s_sel, n);
+                if (n <= kSegThreads) sort_selected<1>(s_sel, n, s_bins);
+                else if (n <= 2 * kSegThreads) sort_selected<2>(s_sel, n, s_bins);
+                else sort_selected<kSelMax / kSegThreads>(s_sel, n, s_bins);
+                // the selection's boxes, decoded once by the whole workgroup into the LDS the unsorted keys leave
+                // free (the walk's wavefronts all look at every tile; a gather per tile and wavefront was a memory
+                // round trip each)
+                float4 *s_cbox = reinterpret_cast<float4 *>(s_keys);
+                static_assert(kSelMax * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "the boxes of a prefix fit where the keys were");
+                for (int i = tid; i < n; i += kSegThreads) s_cbox[i] = box_of(key_row(s_sel[i]));
+                __syncthreads();
+                const int kept = block_nms(s_sel, n, box_of, s_kbox, p.iou_thr, p.max_boxes,
+                                           p.kept_row + (long long)seg * p.max_boxes,
+                                           p.kept_score + (long long)seg * p.max_boxes, s_walk, s_cbox);
                 if (kept >= p.max_boxes || n == cnt) {
                     if (tid == 0) p.kept_cnt[seg] = kept;
                     return;
                 }
+                __syncthreads();
+                for (int i = tid; i < cnt; i += kSegThreads) s_keys[i] = keys[i];      // the boxes took the keys' place
+                __syncthreads();
             }
         }
         sort_prefix(s_keys, cnt);

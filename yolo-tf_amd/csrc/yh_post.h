@@ -164,14 +164,18 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
 // opposite, because the roundings involved stay below 2^-22 relative; only a pair
 // inside the margin, or with a union that is not positive, takes the division.
 // Same decision in every case.
-__device__ __forceinline__ bool suppresses(float ymin_i, float xmin_i, float ymax_i, float xmax_i, float area_i,
-                                           float ymin_j, float xmin_j, float ymax_j, float xmax_j, float area_j,
-                                           float thr)
+// The test in two steps, for callers that look at the intersection of a whole wavefront first: with thr in
+// [0, 1] an intersection that is not positive (zero after the clamp, or NaN) never suppresses.
+__device__ __forceinline__ float intersection(float ymin_i, float xmin_i, float ymax_i, float xmax_i,
+                                              float ymin_j, float xmin_j, float ymax_j, float xmax_j)
 {
-    if (!(area_i > 0.0f && area_j > 0.0f)) return false;    // a NaN area ends in "false" either way
     const float iy = fmaxf(fminf(ymax_i, ymax_j) - fmaxf(ymin_i, ymin_j), 0.0f);
     const float ix = fmaxf(fminf(xmax_i, xmax_j) - fmaxf(xmin_i, xmin_j), 0.0f);
-    const float inter = iy * ix;
+    return iy * ix;
+}
+__device__ __forceinline__ bool suppresses_at(float inter, float area_i, float area_j, float thr)
+{
+    if (!(area_i > 0.0f && area_j > 0.0f)) return false;    // a NaN area ends in "false" either way
     const float uni = (area_i + area_j) - inter;
     const float d = __builtin_fmaf(-thr, uni, inter);
     const float m = __builtin_fmaf(0x1p-20f, uni, 0x1p-100f);
@@ -180,6 +184,12 @@ __device__ __forceinline__ bool suppresses(float ymin_i, float xmin_i, float yma
         if (d < -m) return false;
     }
     return inter / uni > thr;
+}
+__device__ __forceinline__ bool suppresses(float ymin_i, float xmin_i, float ymax_i, float xmax_i, float area_i,
+                                           float ymin_j, float xmin_j, float ymax_j, float xmax_j, float area_j,
+                                           float thr)
+{
+    return suppresses_at(intersection(ymin_i, xmin_i, ymax_i, xmax_i, ymin_j, xmin_j, ymax_j, xmax_j), area_i, area_j, thr);
 }
 
 // Greedy resolve of a tile in score order: a lane is selected iff no SELECTED earlier lane

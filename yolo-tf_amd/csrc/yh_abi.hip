@@ -94,7 +94,7 @@ struct DetectWs {
     unsigned long long *cand, *seg_keys, *ukeys;
     float *boxes, *cand_box, *uboxes;
     int32_t *img_count, *seg_off, *seg_cnt, *class_hist, *class_cursor, *kept_cnt, *kept_row;
-    float *kept_score;
+    float *kept_score, *kept_box;
     size_t zero_begin, zero_bytes;
     size_t bytes;
 };
@@ -123,6 +123,9 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     const size_t o_img = take((size_t)B * 4);
     const size_t o_hist = take((size_t)B * C * 4), o_cur = take((size_t)B * C * 4);
     const size_t o_kc = take((size_t)B * C * 4), o_kr = take((size_t)B * C * mb * 4), o_ks = take((size_t)B * C * mb * 4);
+    // the selected boxes: only the multi-launch select stage passes them from one launch to the next
+    const bool multi = !yh::select_single_launch((int)cap, (int)C, (int)mb);
+    const size_t o_kb = multi ? take((size_t)B * C * mb * 16) : 0;
     w.zero_begin = o_img;
     w.zero_bytes = o_kc - o_img;                 // img_count, class_hist, class_cursor
     w.cand = reinterpret_cast<unsigned long long *>(p + o_cand);
@@ -136,6 +139,7 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     w.kept_cnt = reinterpret_cast<int32_t *>(p + o_kc);
     w.kept_row = reinterpret_cast<int32_t *>(p + o_kr);
     w.kept_score = reinterpret_cast<float *>(p + o_ks);
+    w.kept_box = multi ? reinterpret_cast<float *>(p + o_kb) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -571,7 +575,7 @@ static yh::NmsParams make_nms_params(const DetectWs &w, int32_t B, int32_t C, in
     q.cand = w.cand; q.seg_keys = w.seg_keys; q.img_count = w.img_count;
     q.seg_off = w.seg_off; q.seg_cnt = w.seg_cnt; q.kept_cnt = w.kept_cnt;
     q.class_hist = w.class_hist; q.class_cursor = w.class_cursor;
-    q.kept_row = w.kept_row; q.kept_score = w.kept_score; q.boxes = boxes;
+    q.kept_row = w.kept_row; q.kept_score = w.kept_score; q.kept_box = w.kept_box; q.boxes = boxes;
     q.out_count = out_count; q.out_scores = out_scores; q.out_boxes = out_boxes;
     q.out_class = out_class; q.out_index = out_index; q.out_class_candidates = out_class_candidates;
     q.status = status;
@@ -662,6 +666,12 @@ static int detect_prepare(DetectPlan &d, const yh_head_config *cfg, const float 
                             "boxes it needs from that call's head tensors");
             for (int s = 0; s < p.S; ++s) d.q.src[s].src = prev[s];
         }
+    }
+    if (!(p.wave_ni || p.row_gather) && yh::select_bins_by_slices(max_candidates, p.C, nms_max_boxes)) {
+        // the workgroup-tile kernel counts the classes of the keys it lists: the select stage's first launch
+        // (a pass over the list that counts them) falls away
+        p.class_hist = w.class_hist;
+        d.q.hist_ready = 1;
     }
     if (p.wave_ni || p.row_gather) {          // candidates arrive with slot-indexed boxes
         d.q.upi = p.upi;
@@ -886,9 +896,13 @@ static int nms_impl(int32_t batch, int64_t boxes_per_img, int32_t num_classes,
     p.sc[0].span = (uint32_t)(boxes_per_img * num_classes);
     p.sc[0].grid_w = 1;
     p.sc[0].magic_w = 0xFFFFFFFFu; p.sc[0].magic_p = 0xFFFFFFFFu;
-    const yh::NmsParams q = make_nms_params(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold,
-                                            nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
-                                            out_class, out_index, out_class_candidates, status);
+    yh::NmsParams q = make_nms_params(w, batch, num_classes, (int32_t)boxes_per_img, boxes, iou_threshold,
+                                      nms_max_boxes, max_candidates, out_count, out_scores, out_boxes,
+                                      out_class, out_index, out_class_candidates, status);
+    if (yh::select_bins_by_slices(max_candidates, num_classes, nms_max_boxes)) {
+        p.class_hist = w.class_hist;              // counted where the keys are listed
+        q.hist_ready = 1;
+    }
     const uint32_t blocks = plan_stream(p, batch, yh::kModeConf);
     return run_pipeline(p, yh::kModeConf, blocks, q, st, ev_begin, ev_end);
 }

@@ -121,6 +121,8 @@ struct StreamParams {
     unsigned long long *cand;   // [B][cand_cap]
     float *cand_box;            // [B][cand_cap][4] boxes of the list entries (wave-private variant)
     int32_t *img_count;         // [B], zero on entry; the kernel that consumes it zeroes it again
+    int32_t *class_hist;         // [B][C], or null: the workgroup-tile kernel adds the classes of the keys it lists (the multi-launch
+                                 // select stage then starts from finished counts)
     unsigned long long *ukeys;  // [B][upi][kUnitSlots]
     float *uboxes;              // [B][upi][kUnitSlots][4]
     float *boxes;               // [B][N][4] (workgroup-tile variant and full decode)
@@ -217,6 +219,8 @@ struct NmsParams {
     int32_t *kept_cnt;                 // [B][C]
     int32_t *kept_row;                 // [B][C][max_boxes]
     float *kept_score;                 // [B][C][max_boxes]
+    float *kept_box;                   // [B][C][max_boxes][4]: the selected boxes as decoded (what k_finalize copies out)
+    int32_t hist_ready;                // class_hist holds the list's class counts already (the streaming kernel counted)
     const float *boxes;                // [B][N][4] indexed by box row; null: a box is decoded from the head tensors (src)
     int32_t src_P, src_K, src_C, src_S;   // with boxes == null: the head's geometry, as in StreamParams
     StreamScale src[YH_MAX_SCALES];
@@ -268,6 +272,8 @@ constexpr size_t kFuseLdsMax = 32 * 1024;   // largest LDS block of the stage wh
 
 hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t st);
 bool select_single_launch(int cand_cap, int num_classes, int max_boxes);   // k_post takes the whole stage
+bool select_bins_by_slices(int cand_cap, int num_classes, int max_boxes);  // the multi-launch stage bins a list-only image slice by slice,
+                                                                            // from class counts the workgroup-tile kernel can leave it
 bool select_fits_stream(const NmsParams &p);   // the stage can ride in a streaming launch
 bool select_fits_rows(const NmsParams &p);     // ... in a launch of the objectness-first variant
 constexpr int kRowsThreads = 256;           // objectness-first variant: four wavefronts per workgroup

@@ -171,6 +171,86 @@ __global__ __launch_bounds__(kBinSliceThreads) void k_bin_scatter(const NmsParam
     }
 }
 
+// k_bin_scatter for class counts that leave room in LDS for the slice's keys: the slice (eight keys per thread, held
+// in registers) is brought into class order in LDS first (a counting sort: histogram, scan, placement), and written out in that order, so
+// that the lanes of a store go to a few runs of consecutive keys instead of 64 segments (8-byte stores spread
+// over 64 lines each were what the plain scatter's time went into).  Needs class_hist complete (hist_ready, or
+// k_bin_count ahead of it), like k_bin_scatter.
+constexpr int kSortedSlice = 4096;
+constexpr int kSortedThreads = 512;
+constexpr int kSortedMaxClasses = 1024;          // five class tables of this size beside 32 KiB of keys
+
+__global__ __launch_bounds__(kSortedThreads) void k_bin_scatter_sorted(const NmsParams p, int slices)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_wave[kSortedThreads / 64];
+    unsigned long long *s_out = reinterpret_cast<unsigned long long *>(s_dyn);
+    int *s_tab = reinterpret_cast<int *>(s_out + kSortedSlice);
+    const int b = blockIdx.x / slices, sub = blockIdx.x - b * slices, tid = threadIdx.x, C = p.C, cap = p.cand_cap;
+    int *s_cur = s_tab;              // the image's histogram, then each segment's start
+    int *s_end = s_tab + C;          // count, then each segment's end
+    int *s_mine = s_tab + 2 * C;     // this slice's histogram
+    int *s_loc = s_tab + 3 * C;      // where a class starts in the sorted slice, then its write cursor there
+    int *s_gpos = s_tab + 4 * C;     // global position of a class's keys minus their position in the sorted slice
+    const int raw = p.img_count[b];
+    const int nl = raw < cap ? raw : cap;
+    const int begin = sub * kSortedSlice;
+    const int end = begin + kSortedSlice < nl ? begin + kSortedSlice : nl;
+    if (sub > 0 && begin >= end) return;
+    const int n = end > begin ? end - begin : 0;
+    for (int c = tid; c < C; c += kSortedThreads) { s_cur[c] = p.class_hist[b * C + c]; s_mine[c] = 0; }
+    __syncthreads();
+    for (int c = tid; c < C; c += kSortedThreads) s_end[c] = s_cur[c];
+    const unsigned long long *cand = p.cand + (long long)b * cap + begin;
+    constexpr int kPer = kSortedSlice / kSortedThreads;
+    unsigned long long key[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = tid + j * kSortedThreads;
+        key[j] = i < n ? cand[i] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (tid + j * kSortedThreads < n) atomicAdd(&s_mine[key_class(key[j])], 1);
+    __syncthreads();
+    block_exclusive_scan<kSortedThreads, kSortedMaxClasses / kSortedThreads>(s_cur, C, s_wave);
+    const int found = s_cur[C - 1] + s_end[C - 1];
+    __syncthreads();
+    for (int c = tid; c < C; c += kSortedThreads) {
+        const int o = s_cur[c] < cap ? s_cur[c] : cap;
+        const int m = s_end[c] < cap - o ? s_end[c] : cap - o;
+        if (sub == 0) {
+            p.seg_off[b * C + c] = o;
+            p.seg_cnt[b * C + c] = m;
+            if (p.out_class_candidates) p.out_class_candidates[b * C + c] = m;
+        }
+        s_cur[c] = o;
+        s_end[c] = o + m;
+        s_loc[c] = s_mine[c];
+    }
+    if (sub == 0 && tid == 0) p.status[b] = image_status(found, raw, cap);
+    __syncthreads();
+    block_exclusive_scan<kSortedThreads, kSortedMaxClasses / kSortedThreads>(s_loc, C, s_wave);
+    __syncthreads();
+    for (int c = tid; c < C; c += kSortedThreads) {
+        const int mine = s_mine[c];
+        const int at = mine ? s_cur[c] + atomicAdd(&p.class_cursor[b * C + c], mine) : 0;   // this slice's share of the segment
+        s_gpos[c] = at - s_loc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (tid + j * kSortedThreads < n) s_out[atomicAdd(&s_loc[key_class(key[j])], 1)] = key[j];
+    __syncthreads();
+    unsigned long long *out = p.seg_keys + (long long)b * cap;
+    for (int j = tid; j < n; j += kSortedThreads) {
+        const unsigned long long k = s_out[j];
+        const int c = key_class(k);
+        const int pos = s_gpos[c] + j;
+        if (pos < s_end[c]) out[pos] = k;
+    }
+}
+
 // ---- k_sort_nms: one workgroup per (image, class) segment ------------------------------
 // The greedy walk rarely looks past the first few hundred candidates of a long segment, so a
 // segment that fits into LDS is not sorted whole: a radix selection on the score bits of the
@@ -375,7 +455,8 @@ struct BlockNmsLds {
 
 template <typename BoxOf>
 __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf box_of, float (*kbox)[5],
-                                float thr, int max_boxes, int32_t *krow, float *kscore, BlockNmsLds &l, const float4 *cbox = nullptr)
+                                float thr, int max_boxes, int32_t *krow, float *kscore, float4 *kbox_out, BlockNmsLds &l,
+                                const float4 *cbox = nullptr)
 {
     static_assert(kSegThreads == 256, "sixteen columns of the bit matrix per wavefront");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -455,6 +536,7 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf b
                 kbox[pos][4] = area;
                 krow[pos] = n;
                 kscore[pos] = key_score(key);
+                kbox_out[pos] = bx;
             }
             if (lane == 0) l.kept = kept + __popcll(keepmask);
         }
@@ -488,15 +570,16 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     }
     unsigned long long *keys = p.seg_keys + (long long)b * p.cand_cap + p.seg_off[seg];
     auto box_of = [&](int n) { return row_box(p, b, n); };
+    float4 *seg_boxes = reinterpret_cast<float4 *>(p.kept_box) + (long long)seg * p.max_boxes;
     auto walk = [&](const unsigned long long *sorted, int n) {          // wave 0
         return wave_nms<false>(sorted, n, box_of, nullptr, s_kbox, p.iou_thr, p.max_boxes,
                                p.kept_row + (long long)seg * p.max_boxes,
-                               p.kept_score + (long long)seg * p.max_boxes, nullptr, 0);
+                               p.kept_score + (long long)seg * p.max_boxes, nullptr, 0, seg_boxes);
     };
     auto block_walk = [&](const unsigned long long *sorted, int n) {    // the whole workgroup
         return block_nms(sorted, n, box_of, s_kbox, p.iou_thr, p.max_boxes,
                          p.kept_row + (long long)seg * p.max_boxes,
-                         p.kept_score + (long long)seg * p.max_boxes, s_walk);
+                         p.kept_score + (long long)seg * p.max_boxes, seg_boxes, s_walk);
     };
 
     if (cnt <= 64) {
@@ -539,7 +622,7 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
                 __syncthreads();
                 const int kept = block_nms(s_sel, n, box_of, s_kbox, p.iou_thr, p.max_boxes,
                                            p.kept_row + (long long)seg * p.max_boxes,
-                                           p.kept_score + (long long)seg * p.max_boxes, s_walk, s_cbox);
+                                           p.kept_score + (long long)seg * p.max_boxes, seg_boxes, s_walk, s_cbox);
                 if (kept >= p.max_boxes || n == cnt) {
                     if (tid == 0) p.kept_cnt[seg] = kept;
                     return;
@@ -584,11 +667,10 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const NmsParams p, int
         if (j < kept[c]) {
             const long long src = ((long long)b * C + c) * mb + j;
             const long long dst = (long long)b * cap + s_off[c] + j;
-            const int n = p.kept_row[src];
             p.out_scores[dst] = p.kept_score[src];
-            reinterpret_cast<float4 *>(p.out_boxes)[dst] = row_box(p, b, n);
+            reinterpret_cast<float4 *>(p.out_boxes)[dst] = reinterpret_cast<const float4 *>(p.kept_box)[src];
             p.out_class[dst] = c;
-            p.out_index[dst] = n;
+            p.out_index[dst] = p.kept_row[src];
         }
     }
     if (part == 0 && tid == 0) p.out_count[b] = s_off[C - 1] + kept[C - 1];
@@ -598,6 +680,11 @@ bool select_single_launch(int cand_cap, int num_classes, int max_boxes)
 {
     return cand_cap <= kPostCap && num_classes <= kPostMaxClasses && max_boxes <= kPostMaxBoxes &&
            num_classes * max_boxes <= kPostKeptMax;
+}
+
+bool select_bins_by_slices(int cand_cap, int num_classes, int max_boxes)
+{
+    return !select_single_launch(cand_cap, num_classes, max_boxes) && cand_cap > kBinSlice;
 }
 
 static bool single_launch_shape(const NmsParams &p) { return select_single_launch(p.cand_cap, p.C, p.max_boxes); }
@@ -623,12 +710,21 @@ hipError_t launch_nms_pipeline(const NmsParams &p, hipStream_t stm)
         return hipGetLastError();
     }
     hipError_t e;
-    if (p.upi == 0 && !p.boxes_fill && !p.cand_box && p.cand_cap > kBinSlice) {
+    if (p.upi == 0 && !p.boxes_fill && !p.cand_box && select_bins_by_slices(p.cand_cap, p.C, p.max_boxes)) {
         const int slices = (p.cand_cap + kBinSlice - 1) / kBinSlice;
         const dim3 grid((uint32_t)p.B * (uint32_t)slices);
-        hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinSliceThreads), (size_t)p.C * sizeof(int), stm, p, slices);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinSliceThreads), (size_t)p.C * 3 * sizeof(int), stm, p, slices);
+        if (!p.hist_ready) {
+            hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinSliceThreads), (size_t)p.C * sizeof(int), stm, p, slices);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (p.C <= kSortedMaxClasses) {
+            const int wide = (p.cand_cap + kSortedSlice - 1) / kSortedSlice;
+            const size_t lds = (size_t)kSortedSlice * sizeof(unsigned long long) + (size_t)p.C * 5 * sizeof(int);
+            if ((e = raise_lds_limit(reinterpret_cast<const void *>(k_bin_scatter_sorted), lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_bin_scatter_sorted, dim3((uint32_t)p.B * (uint32_t)wide), dim3(kSortedThreads), lds, stm, p, wide);
+        } else {
+            hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinSliceThreads), (size_t)p.C * 3 * sizeof(int), stm, p, slices);
+        }
     } else {
         hipLaunchKernelGGL(k_bin, dim3(p.B), dim3(kBinThreads), 0, stm, p);
     }

@@ -233,7 +233,7 @@ __device__ __forceinline__ unsigned long long resolve_tile(unsigned long long al
 template <bool IN_LDS, typename BoxOf>
 __device__ inline int wave_nms(const unsigned long long *keys, int cnt, BoxOf box_of,
                                const float4 *boxes_seg, float (*kbox)[5], float thr, int max_boxes,
-                               int32_t *krow, float *kscore, uint16_t *kpos, int pos_base)
+                               int32_t *krow, float *kscore, uint16_t *kpos, int pos_base, float4 *kbox_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int kept = 0;
@@ -276,6 +276,7 @@ __device__ inline int wave_nms(const unsigned long long *keys, int cnt, BoxOf bo
             } else {
                 krow[pos] = n;
                 kscore[pos] = key_score(key);
+                if (kbox_out) kbox_out[pos] = bx;
             }
         }
         kept += __popcll(keepmask);

@@ -52,6 +52,9 @@ struct Stage {
     int base;
 };
 
+// Classes of the keys this workgroup has put on the image's list (dynamic LDS, [C], when the launch counts them).
+extern __shared__ int s_class_hist[];
+
 __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p, int b,
                                                unsigned long long key)
 {
@@ -60,7 +63,10 @@ __device__ __forceinline__ void push_candidate(Stage &st, const StreamParams &p,
         st.keys[slot] = key;
     } else {
         const int g = atomicAdd(&p.img_count[b], 1);
-        if ((uint32_t)g < (uint32_t)p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = key;
+        if ((uint32_t)g < (uint32_t)p.cand_cap) {
+            p.cand[(long long)b * p.cand_cap + g] = key;
+            if (p.class_hist) atomicAdd(&s_class_hist[key_class(key)], 1);
+        }
     }
 }
 
@@ -79,7 +85,11 @@ __device__ __forceinline__ void flush_candidates(Stage &st, const StreamParams &
         const int base = st.base;
         for (int i = tid; i < cnt; i += kTileThreads) {
             const int g = base + i;
-            if ((uint32_t)g < (uint32_t)p.cand_cap) p.cand[(long long)b * p.cand_cap + g] = st.keys[i];
+            if ((uint32_t)g < (uint32_t)p.cand_cap) {
+                const unsigned long long key = st.keys[i];
+                p.cand[(long long)b * p.cand_cap + g] = key;
+                if (p.class_hist) atomicAdd(&s_class_hist[key_class(key)], 1);
+            }
         }
         __syncthreads();
         if (tid == 0) st.count = 0;
@@ -94,6 +104,8 @@ __global__ __launch_bounds__(kTileThreads) void k_stream(const StreamParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wavefront's number, known to be uniform
     if (tid == 0) { st.count = 0; st.nhits = 0; }
+    if (p.class_hist)
+        for (int c = tid; c < p.C; c += kTileThreads) s_class_hist[c] = 0;
 
     // A cut is one workgroup's worth of tiles.  Launched with one workgroup per cut the hardware hands them
     // out; launched with fewer (a fixed number per compute unit, so that LDS and wavefront slots stay free
@@ -234,6 +246,16 @@ __global__ __launch_bounds__(kTileThreads) void k_stream(const StreamParams p)
     }
     __syncthreads();
     flush_candidates(st, p, b, st.count);
+    if (p.class_hist) {
+        // the cut's share of the image's class counts (a cut lies in one image): what k_bin_count would count again
+        // from the list
+        __syncthreads();
+        for (int c = tid; c < C; c += kTileThreads) {
+            const int v = s_class_hist[c];
+            if (v) { atomicAdd(&p.class_hist[(long long)b * C + c], v); s_class_hist[c] = 0; }
+        }
+        __syncthreads();
+    }
     }
 }
 
@@ -1232,8 +1254,9 @@ hipError_t launch_stream(const StreamParams &p, StreamMode mode, uint32_t blocks
     if (blocks == 0) return hipSuccess;
     if (p.cuts != blocks || p.grid_blocks == 0 || p.grid_blocks > blocks) return hipErrorInvalidValue;
     const dim3 grid(p.grid_blocks), block(kTileThreads);
-    if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, 0, stm, p);
-    else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, 0, stm, p);
+    const size_t hist_lds = p.class_hist ? (size_t)p.C * sizeof(int) : 0;
+    if (mode == kModeDetect) hipLaunchKernelGGL(k_stream<kModeDetect>, grid, block, hist_lds, stm, p);
+    else hipLaunchKernelGGL(k_stream<kModeConf>, grid, block, hist_lds, stm, p);
     return hipGetLastError();
 }
 

@@ -200,7 +200,7 @@ def load_valu_busy(workload, kernel):
     """Vector-ALU occupancy of a kernel from the committed SQ counter pass (tools/pmc_sq.sh): the share of
     the SIMDs' cycles spent issuing VALU instructions.  SQ_ACTIVE_INST_VALU counts four-cycle issue slots
     summed over all SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines of the 8 XCDs."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_%s_sq.txt' % workload)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_%s_sq.txt' % workload)
     try:
         lines = open(path).read().splitlines()
     except OSError:
@@ -215,7 +215,7 @@ def load_valu_busy(workload, kernel):
     simds, engines = 1024, 32
     busy = 4.0 * vals['SQ_ACTIVE_INST_VALU'] / (simds * vals['SQ_BUSY_CYCLES'] / engines)
     return dict(valu_instructions_per_launch=int(vals.get('SQ_INSTS_VALU', 0)), valu_busy_frac=round(busy, 3),
-                source='profiles/r02_%s_sq.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_sq.sh)' % workload,
+                source='profiles/r03_%s_sq.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_sq.sh)' % workload,
                 note='share of SIMD cycles issuing vector-ALU instructions while the kernel runs' +
                      ('; the loss kernel is bound by vector-ALU issue and its prologue latency, not by HBM'
                       if kernel == 'k_loss_main' else ''))
@@ -592,21 +592,30 @@ def main():
         # the loss kernel alone: event pairs around back-to-back yh_loss calls without the reducer
         runs = []
         if args.loss_prepared:
-            # the preparation is spent by the call it serves, so every call gets a pair of its own with the
-            # preparation ahead of the pair (the pair's own cost, a microsecond or two, is inside the figure)
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(104)]
-            for a, b in evs:
-                a.record(); b.record()
-            for i, (a, b) in enumerate(evs):
-                hd.loss_prepare(head_shapes, gts[i % rotate])
-                a.record()
+            # the preparation is spent by the call it serves: a pool of head objects (a workspace each) is prepared
+            # first, then their loss calls run back to back between one pair of events
+            pool = [y.DetectionHead(C, priors, box_mult, gt_rate) for _ in range(25)]
+            outs_pool = [None] * len(pool)
+
+            def call(j, h):
                 if w.get('backward'):
-                    hd.loss_and_grad(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, grad_scale=0.5 / B)
+                    h.loss_and_grad(sets[j % rotate], gts[j % rotate], 1., 1., 5., 1., 0.5, True, grad_scale=0.5 / B)
                 else:
-                    reuse['out'] = hd.loss(sets[i % rotate], gts[i % rotate], 1., 1., 5., 1., 0.5, True, out=reuse.get('out'))
+                    outs_pool[j] = h.loss(sets[j % rotate], gts[j % rotate], 1., 1., 5., 1., 0.5, True, out=outs_pool[j])
+            for j, h in enumerate(pool):                      # workspaces and outputs exist before anything is timed
+                call(j, h)
+            for _ in range(6):
+                for j, h in enumerate(pool):
+                    h.loss_prepare(head_shapes, gts[j % rotate])
+                torch.cuda.synchronize(dev)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for j, h in enumerate(pool):
+                    call(j, h)
                 b.record()
-            torch.cuda.synchronize(dev)
-            runs = [a.elapsed_time(b) for a, b in evs[4:]]
+                torch.cuda.synchronize(dev)
+                runs.append(a.elapsed_time(b) / len(pool))
+            runs = runs[1:]
         for _ in range(0 if args.loss_prepared else 5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -619,7 +628,7 @@ def main():
             torch.cuda.synchronize(dev)
             runs.append(a.elapsed_time(b) / 100)
         kern_runs = runs
-        timing = (('HIP event pairs around each of 100 prepared library calls (median; yh_loss_prepare ahead of the pair), no all-reduce: '
+        timing = (('HIP event pairs around 5 runs of 25 back-to-back library calls on one stream, each on a workspace prepared before the run (median run), no all-reduce: '
                    if args.loss_prepared else
                    'HIP event pairs around 5 runs of 100 back-to-back library calls on one stream (median run), no all-reduce: ') +
                   ('two launches per call, k_loss_main (loss sums and the gradient tensor in one pass) and '

@@ -522,6 +522,31 @@ def test_long_candidate_lists_are_binned_in_slices(gpu, c_oracle, cap):
     cases.same_detections(staged.per_image(), want)
 
 
+@pytest.mark.parametrize('C', [1100, 300])
+def test_dense_candidates_over_many_classes(gpu, c_oracle, C):
+    """A dense candidate set (capacity beyond the single-launch stage) with more classes than the slice-sorting
+    scatter keeps tables for (1024) and with fewer: the class counts come from the kernel that lists the
+    candidates, the scatter is the plain one above 1024 classes and the sorting one below.  Selections, class
+    counts and the second call on the same workspace against the oracle."""
+    rng = np.random.default_rng(C)
+    B, N = 2, 500
+    yx = rng.uniform(20, 380, size=(B, N, 2)).astype(np.float32)
+    hw = rng.uniform(10, 90, size=(B, N, 2)).astype(np.float32)
+    boxes = np.concatenate([yx - hw / 2, yx + hw / 2], axis=-1).astype(np.float32)
+    conf = rng.uniform(0.0, 1.0, size=(B, N, C)).astype(np.float32)
+    conf[rng.uniform(size=conf.shape) < 0.97] = 0.0                 # about 3 % of the pairs are candidates
+    per_class = (conf >= np.float32(0.05)).sum(axis=1)
+    assert per_class.sum(axis=1).min() > 2048
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    want = c_oracle.nms(boxes, conf, 0.05, 0.4, 5)
+    dboxes, dconf = torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu)
+    for _ in range(2):
+        res = hd.nms(dboxes, dconf, 0.05, 0.4, 5, max_candidates=20480, want_class_candidates=True)
+        assert not res.overflowed()
+        cases.same_detections(res.per_image(), want)
+        assert np.array_equal(res.class_candidates.cpu().numpy(), per_class)
+
+
 def test_long_segment_sorts_in_global_memory(gpu, c_oracle):
     """One class takes every box: a 4000-candidate segment (beyond the LDS sort)."""
     case = cases.stress(grid=20, P=10, C=3)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box: bench lines of this round into gpurun_out/r03/ (steps chained: stops at the first failure).
+# Runs on the GPU box: bench lines into gpurun_out/r03/ (steps chained: stops at the first failure).
 #   tools/run_r03.sh <name>:<bench.py arguments> ...
 set -e
 mkdir -p gpurun_out/r03

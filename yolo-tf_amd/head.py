@@ -139,13 +139,13 @@ class DetectionHead:
         return out
 
     def config_for_shapes(self, shapes):
-        class _Shape:
-            def __init__(self, shape):
-                self.shape = shape
-        return self.config_for([_Shape(s) for s in shapes])
+        """The yh_head_config of head tensors of these shapes ([B, H, W, P*(C+5)] each)."""
+        return self._config_for_grids(tuple((int(s[1]), int(s[2])) for s in shapes))
 
     def config_for(self, heads):
-        grids = tuple((int(h.shape[1]), int(h.shape[2])) for h in heads)
+        return self._config_for_grids(tuple((int(h.shape[1]), int(h.shape[2])) for h in heads))
+
+    def _config_for_grids(self, grids):
         cfg = self._configs.get(grids)
         if cfg is None:
             cfg = self._configs[grids] = make_config(list(grids), self.priors, self.box_mult, self.gt_rate,

@@ -145,6 +145,18 @@ class YOLOv2:
         fn = getattr(self.head_provider, 'l2_loss_sum', None)
         return float(fn()) if fn is not None else 0.0
 
+    def _loss_prepare_ahead(self, images, ground_truth):
+        """The ground-truth half of the loss call, issued before the network runs (yh_loss_prepare): when the
+        batch is shaped like the last one the loss's tables are built while the convolutions run.  Returns the
+        ground truth, on the device and in the form the loss call will find prepared."""
+        last = getattr(self, '_last_step_shapes', None)
+        if last is None or last[0] != tuple(getattr(images, 'shape', ())) or last[2].type != 'cuda':
+            return ground_truth
+        gt = ground_truth.to(last[2]).to(torch.float32).contiguous()
+        if gt.dim() == 3 and gt.shape[0] == last[1][0][0] and gt.shape[2] == 5:
+            self.head.loss_prepare(last[1], gt)
+        return gt
+
     def train_one_epoch(self, lr, writer=None):
         self.is_training = True
         if self.train_initializer is not None:
@@ -153,11 +165,13 @@ class YOLOv2:
         num_iters = self.num_train // self.batch_size
         for i in range(num_iters):
             images, ground_truth = next(self.train_iterator)
-            head = self._head_from(images)
             if not isinstance(ground_truth, torch.Tensor):          # e.g. NumPy batches of records.get_generator
                 ground_truth = torch.as_tensor(np.asarray(ground_truth, dtype=np.float32))
+            ground_truth = self._loss_prepare_ahead(images, ground_truth)
+            head = self._head_from(images)
             ground_truth = ground_truth.to(head.device)
             self.ground_truth = ground_truth
+            self._last_step_shapes = (tuple(getattr(images, 'shape', ())), [tuple(head.shape)], head.device)
             if head.requires_grad:
                 total_loss = self._train_step(head, ground_truth, lr)
             else:                                            # a head without a graph: the loss value only

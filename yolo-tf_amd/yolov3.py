@@ -167,6 +167,19 @@ class YOLOv3:
             step(lr)
         return parallel.global_mean_loss(out)
 
+    def _loss_prepare_ahead(self, images, ground_truth):
+        """The ground-truth half of the loss call, issued before the network runs (yh_loss_prepare): the batch's
+        ground truth goes to the device first, and when the batch is shaped like the last one (so the head
+        tensors' shapes are known before they exist) the loss's tables are built while the convolutions run.
+        Returns the ground truth, on the device and in the form the loss call will find prepared."""
+        last = getattr(self, '_last_step_shapes', None)
+        if last is None or last[0] != tuple(getattr(images, 'shape', ())) or last[2].type != 'cuda':
+            return ground_truth
+        gt = ground_truth.to(last[2]).to(torch.float32).contiguous()
+        if gt.dim() == 3 and gt.shape[0] == last[1][0][0] and gt.shape[2] == 5:
+            self.head.loss_prepare(last[1], gt)
+        return gt
+
     def _weight_l2(self):
         fn = getattr(self.head_provider, 'l2_loss_sum', None)
         return float(fn()) if fn is not None else 0.0
@@ -180,11 +193,13 @@ class YOLOv3:
         num_iters = self.num_train // self.batch_size
         for i in range(num_iters):
             images, ground_truth = next(self.train_iterator)
-            heads = self._heads_from(images)
             if not isinstance(ground_truth, torch.Tensor):          # e.g. NumPy batches of records.get_generator
                 ground_truth = torch.as_tensor(np.asarray(ground_truth, dtype=np.float32))
+            ground_truth = self._loss_prepare_ahead(images, ground_truth)
+            heads = self._heads_from(images)
             ground_truth = ground_truth.to(heads[0].device)
             self.ground_truth = ground_truth
+            self._last_step_shapes = (tuple(getattr(images, 'shape', ())), [tuple(h.shape) for h in heads], heads[0].device)
             if any(h.requires_grad for h in heads):
                 total_loss = self._train_step(heads, ground_truth, lr, 0.5)
             else:                                            # heads without a graph: the loss value only

@@ -688,6 +688,37 @@ def test_nms_prefix_selection_at_the_largest_max_boxes(gpu, c_oracle, mb):
     assert max(len(g[0]) for g in got) > mb
 
 
+@pytest.mark.parametrize('dist', ['ties', 'one_value_band', 'log_uniform', 'two_bands', 'half_zero_bits'])
+def test_prefix_selection_over_awkward_score_distributions(gpu, c_oracle, dist):
+    """Segments of about 1500 candidates (sorted in LDS through a selected prefix that is grouped by two
+    score bytes and ranked inside its groups) with scores that make those groups degenerate: a handful of
+    distinct values (ties resolved by row, groups of hundreds of equal scores), one value band narrower than
+    a group, magnitudes over three decades (many top bytes), two far-apart bands, and scores whose low
+    mantissa bits are all zero.  Overlapping boxes, so the walk often needs more than the prefix."""
+    rng = np.random.default_rng(len(dist))
+    B, N, C = 2, 1500, 2
+    centre = rng.uniform(0, 900, size=(B, N, 2)).astype(np.float32)
+    size = rng.uniform(20, 160, size=(B, N, 2)).astype(np.float32)
+    boxes = np.concatenate([centre - size / 2, centre + size / 2], axis=-1).astype(np.float32)
+    u = rng.uniform(size=(B, N, C))
+    if dist == 'ties':
+        conf = rng.choice(np.array([0.3, 0.55, 0.5500001, 0.8, 0.95], np.float32), size=(B, N, C))
+    elif dist == 'one_value_band':
+        conf = (0.75 + 1e-5 * u).astype(np.float32)
+    elif dist == 'log_uniform':
+        conf = np.exp(np.log(2e-3) + u * (np.log(1.0) - np.log(2e-3))).astype(np.float32)
+    elif dist == 'two_bands':
+        conf = np.where(u < 0.1, 0.9 + 0.05 * u, 0.01 + 0.001 * u).astype(np.float32)
+    else:
+        conf = (np.floor(u * 64) / 64 + 1 / 128).astype(np.float32)
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    for mb in (20, 100):
+        got = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), 0.001, 0.45, mb,
+                     max_candidates=N * C).per_image()
+        want = c_oracle.nms(boxes, conf, 0.001, 0.45, mb)
+        cases.same_detections(got, want)
+
+
 def test_loss_at_the_largest_ground_truth_block(gpu, c_oracle):
     """pad 2048 (the documented bound): 90 KiB of LDS for the ground-truth block, beyond the
     default limit of dynamic LDS."""

@@ -304,7 +304,9 @@ int yh_loss_workspace_bytes(const yh_head_config *cfg, int32_t batch, int32_t pa
  * yh_loss_forward / yh_loss_with_grad call on that workspace then skips that
  * work in every one of its workgroups if it is a call for the same cfg,
  * ground_truth pointer, batch and pad (and takes its usual path, same results
- * bit for bit, if it is not).  The ground truth must not change in between.
+ * bit for bit, if it is not).  The ground truth must not change in between,
+ * and neither may the workspace's memory be released or rewritten: the record
+ * is by address, and a loss call that matches it trusts what it finds there.
  * The library keeps the record of prepared workspaces (a small table, the
  * oldest entry is dropped); the same workspace size as yh_loss. */
 int yh_loss_prepare(const yh_head_config *cfg, const float *ground_truth, int32_t batch, int32_t pad,

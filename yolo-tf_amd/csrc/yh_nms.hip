@@ -546,6 +546,24 @@ __device__ inline int block_nms(const unsigned long long *keys, int cnt, BoxOf b
     return kept;
 }
 
+#ifdef YH_ROWS_TRACE
+// measurement build: thread 0 of a segment's workgroup stamps the phases of k_sort_nms (tools/trace_sort.py)
+constexpr int kSortTraceSegs = 1 << 14, kSortTraceWords = 8;
+__device__ unsigned long long g_sort_trace[kSortTraceSegs * kSortTraceWords];
+#define YH_ST(i) do { if (threadIdx.x == 0 && blockIdx.x < (unsigned)kSortTraceSegs) g_sort_trace[(size_t)blockIdx.x * kSortTraceWords + (i)] = wall_clock64(); } while (0)
+extern "C" int yh_trace_sort_read(void *dst, size_t bytes, int clear)
+{
+    const size_t have = sizeof(unsigned long long) * kSortTraceSegs * kSortTraceWords;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_sort_trace));
+    if (e != hipSuccess) return (int)e;
+    if (clear) return (int)hipMemset(ptr, 0, have);
+    return (int)hipMemcpy(dst, ptr, bytes < have ? bytes : have, hipMemcpyDeviceToHost);
+}
+#else
+#define YH_ST(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
 {
     __shared__ unsigned long long s_keys[kSortLds];
@@ -558,6 +576,7 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     __shared__ BlockNmsLds s_walk;
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int b = seg / p.C;
+    YH_ST(0);
     const int cnt = p.seg_cnt[seg];
     if (tid == 0) {                           // the binning's counters, clean for the next call
         p.class_hist[seg] = 0;
@@ -605,14 +624,17 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
     if (cnt <= kSortLds) {
         for (int i = tid; i < cnt; i += kSegThreads) s_keys[i] = keys[i];
         __syncthreads();
+        YH_ST(1);
         // a prefix of about 240 keys sorts as 256 (the selection overshoots its target by a few keys)
         const int target = prefix_target(p.max_boxes);
         if (cnt >= 2 * target && sel_room > 0) {
             const int n = select_prefix(s_keys, cnt, target, sel_room, s_sel, s_ctl, s_bins);
+            YH_ST(2);
             if (n > 0) {
                 if (n <= kSegThreads) sort_selected<1>(s_sel, n, s_bins);
                 else if (n <= 2 * kSegThreads) sort_selected<2>(s_sel, n, s_bins);
                 else sort_selected<kSelMax / kSegThreads>(s_sel, n, s_bins);
+                YH_ST(3);
                 // the selection's boxes, decoded once by the whole workgroup into the LDS the unsorted keys leave
                 // free (the walk's wavefronts all look at every tile; a gather per tile and wavefront was a memory
                 // round trip each)
@@ -620,9 +642,18 @@ __global__ __launch_bounds__(kSegThreads) void k_sort_nms(const NmsParams p)
                 static_assert(kSelMax * sizeof(float4) <= kSortLds * sizeof(unsigned long long), "the boxes of a prefix fit where the keys were");
                 for (int i = tid; i < n; i += kSegThreads) s_cbox[i] = box_of(key_row(s_sel[i]));
                 __syncthreads();
+                YH_ST(4);
                 const int kept = block_nms(s_sel, n, box_of, s_kbox, p.iou_thr, p.max_boxes,
                                            p.kept_row + (long long)seg * p.max_boxes,
                                            p.kept_score + (long long)seg * p.max_boxes, seg_boxes, s_walk, s_cbox);
+                YH_ST(5);
+#ifdef YH_ROWS_TRACE
+                if (tid == 0 && blockIdx.x < (unsigned)kSortTraceSegs) {
+                    g_sort_trace[(size_t)blockIdx.x * kSortTraceWords + 6] = ((unsigned long long)cnt << 40) | ((unsigned long long)n << 20) | (unsigned long long)kept;
+                    g_sort_trace[(size_t)blockIdx.x * kSortTraceWords + 7] = 1ull | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) |
+                        ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 40);
+                }
+#endif
                 if (kept >= p.max_boxes || n == cnt) {
                     if (tid == 0) p.kept_cnt[seg] = kept;
                     return;

@@ -1,6 +1,9 @@
 """Property tests (hypothesis): random head geometries, thresholds and ground truth, the HIP path
 through the C ABI against the C oracle.  Bounded example counts and derandomised draws, so the GPU
-run is short and repeats itself."""
+run is short and repeats itself.  YH_PROPERTY_EXAMPLES=n in the environment turns the same properties
+into a soak: n examples each, drawn afresh (tools/soak.sh)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,7 +15,16 @@ from tests.test_gpu_parity import to_dev, assert_close, RTOL
 
 pytestmark = pytest.mark.gpu
 
-SETTINGS = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+SOAK = int(os.environ.get('YH_PROPERTY_EXAMPLES', '0'))
+SETTINGS = dict(deadline=None, derandomize=SOAK == 0, database=None, suppress_health_check=list(HealthCheck))
+
+
+MAX_GRID = 7 if SOAK == 0 else int(os.environ.get('YH_PROPERTY_GRID', '26'))     # the soak also draws grids of several workgroups
+MAX_PAD = 40 if SOAK == 0 else 130
+
+
+def examples(n):
+    return SOAK or n
 
 
 @st.composite
@@ -20,7 +32,7 @@ def geometries(draw, max_classes=300):
     S = draw(st.integers(1, 4))
     P = draw(st.sampled_from([1, 2, 3, 5, 9, 16]))
     C = draw(st.sampled_from([1, 2, 3, 20, 59, 64, 65, 80, 128, 129, max_classes]))
-    grids = [(draw(st.integers(1, 7)), draw(st.integers(1, 7))) for _ in range(S)]
+    grids = [(draw(st.integers(1, MAX_GRID)), draw(st.integers(1, MAX_GRID))) for _ in range(S)]
     seed = draw(st.integers(0, 2 ** 31 - 1))
     rng = np.random.Generator(np.random.PCG64(seed))
     priors = [rng.uniform(0.3, 4.0, size=(P, 2)).astype(np.float32) for _ in range(S)]
@@ -30,7 +42,7 @@ def geometries(draw, max_classes=300):
     return cases.Case('prop', grids, priors, mult, rate, C, size, 3), seed
 
 
-@settings(max_examples=30, **SETTINGS)
+@settings(max_examples=examples(30), **SETTINGS)
 @given(geo=geometries(), B=st.integers(1, 3),
        thr=st.sampled_from([0.0, 1e-3, 0.05, 0.3, 0.5, 0.9, 1.0]), iou=st.sampled_from([0.0, 0.3, 0.5, 1.0]),
        mb=st.sampled_from([1, 3, 10, 100]), obj_mean=st.sampled_from([-3.0, 0.0, 3.0]))
@@ -64,7 +76,7 @@ def test_detect_stages_against_the_oracle(gpu, c_oracle, geo, B, thr, iou, mb, o
 @st.composite
 def ground_truths(draw, case, B):
     """[B, pad, 5] with duplicates, zero-area rows, centres outside the image and ragged counts."""
-    pad = draw(st.integers(2, 40))
+    pad = draw(st.integers(2, MAX_PAD))
     seed = draw(st.integers(0, 2 ** 31 - 1))
     rng = np.random.Generator(np.random.PCG64(seed))
     gt = np.full((B, pad, 5), -1.0, np.float32)
@@ -83,7 +95,7 @@ def ground_truths(draw, case, B):
     return gt
 
 
-@settings(max_examples=25, **SETTINGS)
+@settings(max_examples=examples(25), **SETTINGS)
 @given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 3), version=st.sampled_from([2, 3]),
        thr=st.sampled_from([0.0, 0.3, 0.5, 0.6, 1.0]))
 def test_loss_against_the_oracle(gpu, c_oracle, data, geo, B, version, thr):
@@ -103,3 +115,42 @@ def test_loss_against_the_oracle(gpu, c_oracle, data, geo, B, version, thr):
     assert_close(out['per_image'].cpu().numpy(), per, rtol=RTOL, atol=1e-6, what='per-image loss')
     fast = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True)
     assert np.array_equal(fast['parts'].cpu().numpy().view(np.uint32), out['parts'].cpu().numpy().view(np.uint32))
+
+
+@settings(max_examples=examples(20), **SETTINGS)
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 4), version=st.sampled_from([2, 3]),
+       thr=st.sampled_from([0.0, 0.3, 0.5, 0.6, 1.0]), exact=st.booleans())
+def test_loss_gradient_paths_agree(gpu, data, geo, B, version, thr, exact):
+    """The three ways to the gradient give the same bits on random geometries and ground truth with
+    duplicated rows (several rows assigned one box): forward then backward, the fused pass, and the
+    fused pass on a prepared workspace; the fused pass twice gives the same bits twice; the
+    forward outputs of all of them are those of the plain forward call."""
+    case, seed = geo
+    gt = data.draw(ground_truths(case, B))
+    heads = case.heads(seed % 7907, B, obj_mean=-1.0)
+    norm = version == 3
+    scales = (1.0, 0.5, 5.0, 2.0)
+    dheads, dgt = to_dev(heads, gpu), torch.from_numpy(gt).to(gpu)
+    gw = torch.linspace(0.25, 1.5, B, device=gpu)
+    hd = case.head_obj()
+    fwd = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=exact, want_mask=True)
+    two = hd.loss_backward(dheads, dgt, *scales, norm, fwd['noobj_mask'], gw)
+    fused = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=exact, grad_per_image=gw)
+    again = [g.clone() for g in hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=exact,
+                                        grad_per_image=gw)['grads']]
+    other = case.head_obj()
+    other.loss_prepare([tuple(h.shape) for h in dheads], dgt)
+    prepared = other.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=exact, grad_per_image=gw)
+    other.loss_prepare(dheads, dgt)
+    prepared_fwd = other.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_iou_max=exact, want_mask=True)
+
+    def same(a, b):
+        return a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=7e30, neginf=-7e30),
+                                                  torch.nan_to_num(b, nan=-7.0, posinf=7e30, neginf=-7e30))
+    for k in ('per_image', 'sum', 'parts') + (('iou_max',) if exact else ()):
+        assert same(fused[k], fwd[k]) and same(prepared[k], fwd[k]) and same(prepared_fwd[k], fwd[k]), k
+    assert torch.equal(prepared_fwd['noobj_mask'], fwd['noobj_mask'])
+    for s in range(len(two)):
+        assert same(fused['grads'][s], two[s]), ('fused against two calls', s)
+        assert same(again[s], two[s]), ('second fused call', s)
+        assert same(prepared['grads'][s], two[s]), ('prepared', s)

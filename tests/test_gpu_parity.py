@@ -688,6 +688,36 @@ def test_nms_prefix_selection_at_the_largest_max_boxes(gpu, c_oracle, mb):
     assert max(len(g[0]) for g in got) > mb
 
 
+@pytest.mark.parametrize('group_of_wave', [0, 1, 2, 3])
+@pytest.mark.parametrize('left', [1, 2, 3])
+def test_tile_kernel_reads_the_partial_last_slot_of_a_tensor(gpu, left, group_of_wave):
+    """A confidence matrix whose float count is not a multiple of four ends in a partial 16-byte slot, which the
+    workgroup-tile kernel stores into its LDS tile with a plain store of wavefront 0, while the window's last
+    group of whole slots is an LDS-DMA load of whichever wavefront the group falls to, with its lanes past the
+    end switched off (a lane that wrote there too would race with that store: seen once in some 70000 first
+    calls as a count that was one short, the partial slot holding a copy of the slot before it).  The only
+    candidates are the partial slot's floats, then only the last whole slot's; either way the counts and the
+    kept rows are exact, with the group on each of the four wavefronts."""
+    B, C = 1, 1
+    whole = 64 * (12 + group_of_wave) + 37                      # whole slots: the last group is the tile's 13th..16th
+    N = 4 * whole + left
+    boxes = np.zeros((B, N, 4), np.float32)
+    boxes[0, :, 0] = boxes[0, :, 1] = 100.0 * np.arange(N, dtype=np.float32)      # nothing overlaps
+    boxes[0, :, 2:] = boxes[0, :, :2] + 10.0
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    for which in ('partial', 'before'):
+        conf = np.full((B, N, C), 0.01, np.float32)
+        rows = np.arange(4 * whole, N) if which == 'partial' else np.arange(4 * whole - 4, 4 * whole)
+        conf[0, rows, 0] = np.linspace(0.9, 0.6, len(rows), dtype=np.float32)
+        for _ in range(3):
+            res = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), 0.3, 0.5, 20,
+                         max_candidates=N * C, want_class_candidates=True)
+            assert not res.overflowed()
+            assert res.class_candidates.cpu().numpy().tolist() == [[len(rows)]], which
+            got = res.per_image()[0]
+            assert got[3].tolist() == rows.tolist() and np.array_equal(got[0], conf[0, rows, 0]), which
+
+
 @pytest.mark.parametrize('dist', ['ties', 'one_value_band', 'log_uniform', 'two_bands', 'half_zero_bits'])
 def test_prefix_selection_over_awkward_score_distributions(gpu, c_oracle, dist):
     """Segments of about 1500 candidates (sorted in LDS through a selected prefix that is grouped by two

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, event, given, settings, strategies as st
 
 import yolo_tf_amd as y
 from tests import cases
@@ -15,8 +15,12 @@ from tests.test_gpu_parity import to_dev, assert_close, RTOL
 
 pytestmark = pytest.mark.gpu
 
+if os.environ.get('YH_TEST_LIB'):                   # a soak of another build of the library (a file beside the shipped one)
+    from yolo_tf_amd import _abi
+    _abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), os.environ['YH_TEST_LIB'])
+
 SOAK = int(os.environ.get('YH_PROPERTY_EXAMPLES', '0'))
-SETTINGS = dict(deadline=None, derandomize=SOAK == 0, database=None, suppress_health_check=list(HealthCheck))
+SETTINGS = dict(deadline=None, derandomize=SOAK == 0, database=None, print_blob=True, suppress_health_check=list(HealthCheck))
 
 
 MAX_GRID = 7 if SOAK == 0 else int(os.environ.get('YH_PROPERTY_GRID', '26'))     # the soak also draws grids of several workgroups
@@ -154,3 +158,86 @@ def test_loss_gradient_paths_agree(gpu, data, geo, B, version, thr, exact):
         assert same(fused['grads'][s], two[s]), ('fused against two calls', s)
         assert same(again[s], two[s]), ('second fused call', s)
         assert same(prepared['grads'][s], two[s]), ('prepared', s)
+
+
+@st.composite
+def candidate_sets(draw):
+    """Decoded boxes [B, N, 4] and confidences [B, N, C] whose class segments range from empty to
+    several thousand candidates, with score distributions that make a radix selection's groups
+    degenerate and box layouts from sparse to heavily overlapping."""
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    B = draw(st.integers(1, 3))
+    C = draw(st.sampled_from([1, 2, 3, 5, 17, 80, 300, 1100]))
+    N = draw(st.sampled_from([1, 7, 64, 65, 300, 1500] + ([2049, 4000, 6000] if SOAK else []))) + draw(st.integers(0, 50))
+    N = max(1, min(N, 1500000 // (B * C)))
+    layout = draw(st.sampled_from(['spread', 'clustered', 'nested', 'degenerate']))
+    if layout == 'clustered':
+        k = int(rng.integers(1, 12))
+        centre = rng.uniform(60, 340, size=(B, k, 2))
+        size = rng.uniform(30, 120, size=(B, k, 2))
+        which = rng.integers(0, k, size=(B, N))
+        c = np.take_along_axis(centre, which[..., None], axis=1) + rng.normal(0, 6, size=(B, N, 2))
+        sz = np.take_along_axis(size, which[..., None], axis=1) * rng.uniform(0.8, 1.25, size=(B, N, 2))
+    elif layout == 'nested':
+        c = np.full((B, N, 2), 200.0) + rng.normal(0, 1, size=(B, N, 2))
+        sz = rng.uniform(1, 400, size=(B, N, 2))
+    else:
+        c = rng.uniform(0, float(draw(st.sampled_from([300, 900, 3000]))), size=(B, N, 2))
+        sz = rng.uniform(10, 160, size=(B, N, 2))
+    boxes = np.concatenate([c - sz / 2, c + sz / 2], axis=-1).astype(np.float32)
+    if layout == 'degenerate':
+        kind = rng.integers(0, 5, size=(B, N))
+        boxes[kind == 0, 2:] = boxes[kind == 0, :2]                      # zero area
+        boxes[kind == 1] = boxes[kind == 1][:, [2, 3, 0, 1]]             # corners the other way round
+        boxes[kind == 2] = boxes[0, 0]                                   # copies of one box
+    u = rng.uniform(size=(B, N, C))
+    dist = draw(st.sampled_from(['uniform', 'ties', 'one_value_band', 'log_uniform', 'two_bands', 'half_zero_bits']))
+    if dist == 'ties':
+        conf = rng.choice(np.array([0.3, 0.55, 0.5500001, 0.8, 0.95], np.float32), size=(B, N, C))
+    elif dist == 'one_value_band':
+        conf = (0.75 + 1e-5 * u).astype(np.float32)
+    elif dist == 'log_uniform':
+        conf = np.exp(np.log(2e-3) + u * (np.log(1.0) - np.log(2e-3))).astype(np.float32)
+    elif dist == 'two_bands':
+        conf = np.where(u < 0.1, 0.9 + 0.05 * u, 0.01 + 0.001 * u).astype(np.float32)
+    elif dist == 'half_zero_bits':
+        conf = (np.floor(u * 64) / 64 + 1 / 128).astype(np.float32)
+    else:
+        conf = u.astype(np.float32)
+    conf = conf.astype(np.float32)
+    conf[rng.uniform(size=conf.shape) < draw(st.sampled_from([0.0, 0.5, 0.97, 0.999]))] = 0.0
+    return boxes, conf
+
+
+@settings(max_examples=examples(12), **SETTINGS)
+@given(cs=candidate_sets(), thr=st.sampled_from([0.001, 0.05, 0.3, 0.6]), iou=st.sampled_from([0.0, 0.3, 0.45, 0.5, 0.7, 1.0]),
+       mb=st.sampled_from([1, 5, 20, 100, 200, 512]), tight=st.booleans())
+def test_nms_stage_on_random_candidate_sets(gpu, c_oracle, cs, thr, iou, mb, tight):
+    """Score filter + per-class NMS on given boxes and confidences against the oracle: kept rows,
+    classes, scores and boxes bit for bit and the per-class candidate counts, whatever launch
+    shape the candidate capacity selects (the default one, or room for every pair)."""
+    boxes, conf = cs
+    B, N, C = conf.shape
+    longest = int((conf >= np.float32(thr)).sum(axis=1).max())
+    event('longest class segment: %s' % ('0' if longest == 0 else '<= 64' if longest <= 64 else '<= 2048' if longest <= 2048 else '> 2048'))
+    event('candidates of an image: %s' % ('<= 2048' if (conf >= np.float32(thr)).sum(axis=(1, 2)).max() <= 2048 else '> 2048'))
+    hd = y.DetectionHead(C, [np.ones((1, 2), np.float32)], [1.0], [1.0])
+    res = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), thr, iou, mb,
+                 max_candidates=None if tight else N * C, want_class_candidates=True).resolved()
+    want = c_oracle.nms(boxes, conf, thr, iou, mb)
+    got = res.per_image()
+    cases.same_detections(got, want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0].view(np.uint32), w[0].view(np.uint32))
+        assert np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32))
+        assert np.array_equal(g[3], w[3])
+    got_cc, want_cc = res.class_candidates.cpu().numpy(), (conf >= np.float32(thr)).sum(axis=1).astype(np.int32)
+    if os.environ.get('YH_PROPERTY_DUMP') and not np.array_equal(got_cc, want_cc):      # what a soak keeps of a failure
+        again = hd.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(conf).to(gpu), thr, iou, mb,
+                       max_candidates=None if tight else N * C, want_class_candidates=True).resolved()
+        np.savez(os.path.join(os.environ['YH_PROPERTY_DUMP'], 'nms_cc_%d_%d_%d.npz' % (B, N, C)), boxes=boxes, conf=conf,
+                 thr=thr, iou=iou, mb=mb, tight=tight, got=got_cc, want=want_cc, status=res.status.cpu().numpy(),
+                 count=res.count.cpu().numpy(), again=again.class_candidates.cpu().numpy())
+    assert np.array_equal(got_cc, want_cc), ('class candidates', got_cc[got_cc != want_cc][:8], want_cc[got_cc != want_cc][:8],
+                                             np.argwhere(got_cc != want_cc)[:8].tolist(), B, N, C)

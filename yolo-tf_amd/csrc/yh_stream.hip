@@ -153,9 +153,12 @@ __global__ __launch_bounds__(kTileThreads) void k_stream(const StreamParams p)
             const int slot0 = (j * (kTileThreads / 64) + wave_u) * 64;
             if (slot0 + 64 <= ndma) {
                 __builtin_amdgcn_global_load_lds((gptr_t *)(lane_src + slot0), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
-            } else if (slot0 < ndma) {                        // the window's last group: lanes past the end re-read the last slot
-                const int slot = slot0 + lane < ndma ? slot0 + lane : ndma - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(src4 + q0 + slot), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
+            } else if (slot0 < ndma) {
+                // The window's last group: the lanes past the end load nothing.  (A lane that re-read the last
+                // slot instead would also write the LDS slots behind it, and slot ndma is where another
+                // wavefront's plain store puts the tensor's partial slot below: the later of the two would win.)
+                if (slot0 + lane < ndma)
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(lane_src + slot0), (lptr_t *)(st.tile + slot0 * 4), 16, 0, 0);
             }
         }
         if (ndma < wslots) {                                  // the tensor's last, partial slot: 1..3 floats

@@ -25,6 +25,7 @@ SETTINGS = dict(deadline=None, derandomize=SOAK == 0, database=None, print_blob=
 
 MAX_GRID = 7 if SOAK == 0 else int(os.environ.get('YH_PROPERTY_GRID', '26'))     # the soak also draws grids of several workgroups
 MAX_PAD = 40 if SOAK == 0 else 130
+MAX_B = 3 if SOAK == 0 else 10
 
 
 def examples(n):
@@ -100,7 +101,7 @@ def ground_truths(draw, case, B):
 
 
 @settings(max_examples=examples(25), **SETTINGS)
-@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 3), version=st.sampled_from([2, 3]),
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, MAX_B), version=st.sampled_from([2, 3]),
        thr=st.sampled_from([0.0, 0.3, 0.5, 0.6, 1.0]))
 def test_loss_against_the_oracle(gpu, c_oracle, data, geo, B, version, thr):
     """Ignore-mask IoU maxima bit-identical, loss parts and per-image losses 1e-5, with and without
@@ -122,7 +123,7 @@ def test_loss_against_the_oracle(gpu, c_oracle, data, geo, B, version, thr):
 
 
 @settings(max_examples=examples(20), **SETTINGS)
-@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 4), version=st.sampled_from([2, 3]),
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, MAX_B + 1), version=st.sampled_from([2, 3]),
        thr=st.sampled_from([0.0, 0.3, 0.5, 0.6, 1.0]), exact=st.booleans())
 def test_loss_gradient_paths_agree(gpu, data, geo, B, version, thr, exact):
     """The three ways to the gradient give the same bits on random geometries and ground truth with
@@ -241,3 +242,42 @@ def test_nms_stage_on_random_candidate_sets(gpu, c_oracle, cs, thr, iou, mb, tig
                  count=res.count.cpu().numpy(), again=again.class_candidates.cpu().numpy())
     assert np.array_equal(got_cc, want_cc), ('class candidates', got_cc[got_cc != want_cc][:8], want_cc[got_cc != want_cc][:8],
                                              np.argwhere(got_cc != want_cc)[:8].tolist(), B, N, C)
+
+
+TUNINGS = [dict(), dict(row_steps=1), dict(row_steps=2), dict(row_steps=3), dict(row_steps=5), dict(row_steps=50),
+           dict(detect_kernel=2, stream_tile_kib=1),
+           dict(detect_kernel=2, stream_tile_kib=8, stream_buffers=3, stream_units=8192),
+           dict(detect_kernel=2, stream_tile_kib=8, stream_buffers=2, stream_units=64),
+           dict(detect_kernel=2, stream_tile_kib=4, stream_buffers=2, stream_units=300),
+           dict(detect_kernel=2, stream_tile_kib=4, stream_buffers=3, stream_units=7),
+           dict(detect_kernel=2, stream_tile_kib=4, stream_buffers=4, stream_units=100000)]
+
+
+@settings(max_examples=examples(10), **SETTINGS)
+@given(geo=geometries(), B=st.integers(1, 3), thr=st.sampled_from([1e-3, 0.05, 0.3, 0.5]), iou=st.sampled_from([0.3, 0.5]),
+       mb=st.sampled_from([3, 10, 100]), obj_mean=st.sampled_from([-3.0, 0.0, 3.0]), hot_mean=st.sampled_from([-2.0, 2.0]),
+       cap_kind=st.sampled_from(['default', 'one launch', 'every pair']))
+def test_streaming_kernels_agree_on_random_heads(gpu, geo, B, thr, iou, mb, obj_mean, hot_mean, cap_kind):
+    """The objectness-first kernel at several unit lengths, the workgroup-tile kernel and the
+    wave-private kernel in several shapes give the same detections and class counts from the
+    same head tensors, bit for bit, whatever the geometry: tensors whose float count is not a
+    multiple of four, rows that straddle tiles, few and all rows surviving."""
+    from yolo_tf_amd import _abi
+    case, seed = geo
+    dheads = to_dev(case.heads(seed % 9967, B, obj_mean=obj_mean, hot_mean=hot_mean, cold_mean=-2.0), gpu)
+    cap = {'default': None, 'one launch': min(case.N * case.C, 2048), 'every pair': case.N * case.C}[cap_kind]
+    try:
+        ref = None
+        for t in TUNINGS:
+            _abi.set_tuning(**t)
+            got = case.head_obj().detect(dheads, thr, iou, mb, max_candidates=cap, want_class_candidates=True).resolved()
+            if ref is None:
+                ref = got
+                continue
+            cases.same_detections(got.per_image(), ref.per_image())
+            for a, b in zip(got.per_image(), ref.per_image()):
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), t
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), t
+            assert torch.equal(got.class_candidates, ref.class_candidates), t
+    finally:
+        _abi.set_tuning()

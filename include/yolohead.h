@@ -138,8 +138,10 @@ int yh_decode(const yh_head_config *cfg, const float *const *heads, int32_t batc
 /* Workspace size (host out) for yh_detect with these bounds.
  * The workspace of yh_detect / yh_nms must be ZERO-FILLED once after it is
  * allocated (hipMemset); every call leaves it in a state the next call, with
- * the same arguments to the size query, can start from.  A workspace must not
- * be shared by calls that overlap in time.
+ * the same arguments to the size query, can start from.  The fill must be
+ * complete, or ordered on `stream`, before the first call: a hipMemsetAsync on
+ * another stream is not.  A workspace must not be shared by calls that overlap
+ * in time.
  * max_candidates <= 2048 (with num_classes <= 1024, nms_max_boxes <= 128 and
  * num_classes * nms_max_boxes <= 4096) selects a single-launch form of the
  * candidates -> detections stage; larger capacities take a three-launch form.
@@ -213,7 +215,12 @@ int yh_detect_timed(const yh_head_config *cfg, const float *const *heads, int32_
  *   yh_detect_select      YOLOv3.py:355-368 / YOLOv2.py:197-210: per-class NMS,
  *                         gather, concat, from that workspace.
  * Both take the arguments of the same name of yh_detect, with the same values
- * for the pair; results are those of yh_detect. */
+ * for the pair; results are those of yh_detect.  With max_candidates beyond the
+ * single-launch form yh_detect_select reads the boxes it looks at from the head
+ * tensors of the yh_detect_candidates call on that workspace (leave them as
+ * they are until it has run); the library keeps that call on record for the 64
+ * workspaces streamed into most recently and fails with YH_ERR_INVALID_ARG
+ * for a workspace that is not among them. */
 int yh_detect_candidates(const yh_head_config *cfg, const float *const *heads, int32_t batch,
                          float score_threshold, int32_t nms_max_boxes, int32_t max_candidates,
                          void *workspace, size_t workspace_bytes, void *stream);

@@ -372,6 +372,52 @@ def test_candidates_then_select_calls(gpu):
     assert torch.equal(got.class_candidates, want.class_candidates)
 
 
+def test_select_finds_its_streaming_call_among_many_workspaces(gpu):
+    """With a dense candidate capacity yh_detect_select decodes the boxes it looks at from the head tensors
+    of the yh_detect_candidates call on its workspace, which the library keeps on record for the 64
+    workspaces streamed into most recently.  A workspace that was on record long ago and streams again
+    keeps its record while a few other workspaces stream for the first time (a table that replaced entries
+    in turn, whatever their age, lost it: 'no streaming call on this workspace is on record'); after 64
+    others it is gone and the select call says so."""
+    import ctypes
+    from yolo_tf_amd import _abi
+    case = cases.stress(grid=20, P=10, C=3)                     # 4000 boxes x 3 classes
+    hd = case.head_obj()
+    B, mb = 2, 5
+    heads = y.synth.torch_heads(gpu, 83, B, case.grids, case.P, case.C, obj_mean=0.0)
+    cap = 4096                                                  # beyond the single-launch form: no boxes in the workspace
+    want = hd.detect(heads, 0.05, 0.5, mb, max_candidates=cap)
+    (cfg, _, N, ws0), = hd._plans.values()
+    lib = _abi.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    hp = _abi.pointer_array([h.data_ptr() for h in heads])
+    spaces = [torch.zeros_like(ws0) for _ in range(64 + 70)]
+    outs = hd._alloc_outputs(B, mb, gpu, False)
+
+    def candidates(ws):
+        _abi.check(lib.yh_detect_candidates(ctypes.byref(cfg), hp, B, 0.05, mb, cap, ws.data_ptr(), ws.numel(), st))
+
+    def select(ws):
+        _abi.check(lib.yh_detect_select(ctypes.byref(cfg), B, 0.5, mb, cap, ws.data_ptr(), ws.numel(),
+                                        *[t.data_ptr() if t is not None else None for t in outs], st))
+        cases.same_detections(y.Detections(*outs, None).per_image(), want.per_image())
+
+    for ws in spaces[:64]:                                      # the table is full, in this order
+        candidates(ws)
+        select(ws)
+    mine = spaces[1]
+    candidates(mine)                                            # on record already, and now the most recent
+    for ws in spaces[64:67]:
+        candidates(ws)
+        select(ws)
+    select(mine)
+    for ws in spaces[67:67 + 64]:                               # 64 others since: its record is gone
+        candidates(ws)
+        select(ws)
+    with pytest.raises(_abi.YhError, match='on record'):
+        select(mine)
+
+
 @pytest.mark.parametrize('obj_mean,hot_mean', [(-1.0, 2.0), (0.0, 0.0), (2.0, -1.0), (9.0, -2.0)])
 def test_streaming_variants_agree(gpu, tuning, obj_mean, hot_mean):
     """The objectness-first kernel (the default; one to many steps per work unit), the

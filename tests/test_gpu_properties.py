@@ -281,3 +281,49 @@ def test_streaming_kernels_agree_on_random_heads(gpu, geo, B, thr, iou, mb, obj_
             assert torch.equal(got.class_candidates, ref.class_candidates), t
     finally:
         _abi.set_tuning()
+
+
+@settings(max_examples=examples(10), **SETTINGS)
+@given(geo=geometries(), B=st.integers(1, 3), batches=st.integers(2, 7), lanes=st.integers(1, 3),
+       thr=st.sampled_from([0.05, 0.3, 0.5]), mb=st.sampled_from([3, 10, 100]), obj_mean=st.sampled_from([-3.0, 0.0, 3.0]),
+       cap_kind=st.sampled_from(['default', 'one launch', 'every pair']), kernel=st.sampled_from([0, 1, 2]))
+def test_lanes_match_detect_on_random_heads(gpu, geo, B, batches, lanes, thr, mb, obj_mean, cap_kind, kernel):
+    """DetectLanes (pipelines on streams of their own, a batch's select stage inside or right before
+    the next batch's launch of its lane) gives detect()'s result for every batch of a random
+    sequence, in submission order, bit for bit; a batch whose candidates overflow the capacity is
+    flagged as detect() flags it."""
+    from yolo_tf_amd import _abi
+    case, seed = geo
+    cap = {'default': None, 'one launch': min(case.N * case.C, 2048), 'every pair': case.N * case.C}[cap_kind]
+    try:
+        _abi.set_tuning(detect_kernel=kernel)
+        sets = [to_dev(case.heads((seed + 31 * i) % 9949, B, obj_mean=obj_mean, cold_mean=-2.0), gpu) for i in range(batches)]
+        hd = case.head_obj()
+        want = [hd.detect(h, thr, 0.5, mb, max_candidates=cap, want_class_candidates=True) for h in sets]
+        want = [(w.overflowed(), w.per_image() if not w.overflowed() else None, w.class_candidates.clone()) for w in want]
+        torch.cuda.synchronize()
+        pipe = y.DetectLanes(case.head_obj(), thr, 0.5, mb, lanes=lanes, max_candidates=cap, want_class_candidates=True)
+        def read(d):                                  # at once: a lane's output sets alternate, the second call after this one reuses them
+            ov = d.overflowed()
+            rows = [(s[:k], b[:k], c[:k], r[:k]) for s, b, c, r, k in zip(d.scores.cpu().numpy(), d.boxes.cpu().numpy(),
+                    d.class_id.cpu().numpy(), d.index.cpu().numpy(), d.count.cpu().numpy())]
+            return ov, rows, d.class_candidates.clone()
+        got = []
+        for h in sets:
+            d = pipe.submit(h, wait_current=True)
+            if d is not None:
+                got.append(read(d))
+        for d in pipe.flush():
+            got.append(read(d))
+        assert len(got) == len(want) and pipe.flush() == []
+        for i, ((gov, gi, gc), (ov, w, wc)) in enumerate(zip(got, want)):
+            assert gov == ov, i
+            if ov:
+                continue
+            cases.same_detections(gi, w)
+            for a, b in zip(gi, w):
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), i
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), i
+            assert torch.equal(gc, wc), i
+    finally:
+        _abi.set_tuning()

@@ -159,21 +159,25 @@ DetectWs carve_for_plan(void *base, const yh::StreamParams &p, int64_t B, int64_
 // head tensors.  When the two stages are separate calls (yh_detect_candidates / yh_detect_select, or a batch's
 // select stage riding in the next call of yh_detect_pipelined) the select stage has no head argument of its
 // own: the library remembers, per workspace, the head tensors of the last streaming call on it.  A small
-// table; the oldest entry goes when it is full.
-struct WorkspaceHeads { const void *ws; const float *head[YH_MAX_SCALES]; };
+// table; when it is full the entry whose streaming call is the longest ago goes (a workspace's record is
+// lost only once kWorkspaceHeads OTHER workspaces have had a streaming call since its own).
+struct WorkspaceHeads { const void *ws; const float *head[YH_MAX_SCALES]; unsigned long long stamp; };
 constexpr int kWorkspaceHeads = 64;
 std::mutex g_ws_heads_mu;
 WorkspaceHeads g_ws_heads[kWorkspaceHeads];
-unsigned g_ws_heads_next = 0;
+unsigned long long g_ws_heads_clock = 0;
 
 void remember_heads(const void *ws, const float *const *heads, int S)
 {
     std::lock_guard<std::mutex> lock(g_ws_heads_mu);
-    int at = -1;
-    for (int i = 0; i < kWorkspaceHeads && at < 0; ++i)
+    int at = -1, oldest = 0;
+    for (int i = 0; i < kWorkspaceHeads && at < 0; ++i) {
         if (g_ws_heads[i].ws == ws) at = i;
-    if (at < 0) at = (int)(g_ws_heads_next++ % kWorkspaceHeads);
+        if (g_ws_heads[i].stamp < g_ws_heads[oldest].stamp) oldest = i;      // never used: stamp 0
+    }
+    if (at < 0) at = oldest;
     g_ws_heads[at].ws = ws;
+    g_ws_heads[at].stamp = ++g_ws_heads_clock;
     for (int s = 0; s < YH_MAX_SCALES; ++s) g_ws_heads[at].head[s] = s < S ? heads[s] : nullptr;
 }
 

@@ -4,6 +4,7 @@ describes the head geometry and calls libyolohead through ctypes.
 torch is plumbing here (device memory, streams); every computation happens in
 the HIP kernels behind the C ABI.  Without the shared library or without a HIP
 device these functions raise; nothing falls back to the CPU."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -39,6 +40,15 @@ def make_config(grids, priors, box_mult, gt_rate, num_classes):
             cfg.prior_hw[s][p][0] = float(pr[p, 0])
             cfg.prior_hw[s][p][1] = float(pr[p, 1])
     return cfg
+
+
+def _allocating_on(stream):
+    """Allocations (and the zero fill of a new workspace) for launches that go to `stream`: made with that
+    stream current, so that the fill is ordered before the launches and the caching allocator knows which
+    stream uses the blocks.  (Filled on the caller's current stream, a new workspace could still hold what
+    the block's last owner left in it when a launch on another stream read its counters: seen once in some
+    thousand first calls of a DetectLanes as a stale key at the head of every class's selection.)"""
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
 
 class Detections:
@@ -250,9 +260,10 @@ class DetectionHead:
         dev = heads[0].device
         N = self.boxes_per_image(heads)
         cap = int(max_candidates) if max_candidates is not None else self.default_max_candidates(N)
-        cfg, B, N, ws = self._detect_plan(heads, cap, max_boxes)
-        if outputs is None:
-            outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
+        with _allocating_on(stream):
+            cfg, B, N, ws = self._detect_plan(heads, cap, max_boxes)
+            if outputs is None:
+                outputs = self._alloc_outputs(B, int(max_boxes), dev, want_class_candidates)
         args = [ctypes.byref(cfg), _abi.pointer_array([h.data_ptr() for h in heads]), B,
                 float(score_threshold), float(iou_threshold), int(max_boxes), cap,
                 ws.data_ptr(), ws.numel()] + self._output_pointers(outputs) + [
@@ -602,12 +613,14 @@ class DetectPipeline:
         N = hd.boxes_per_image(heads)
         cap = int(self.cap) if self.cap is not None else hd.default_max_candidates(N)
         slot = self._i & 1
-        cfg, B, N, ws = hd._detect_plan(heads, cap, self.max_boxes, slot=('pipe', self.tag, slot))
+        with _allocating_on(self.stream):
+            cfg, B, N, ws = hd._detect_plan(heads, cap, self.max_boxes, slot=('pipe', self.tag, slot))
         prev = self._prev
         if prev is not None and (prev[1] != B or prev[5] != cap or bytes(prev[0]) != bytes(cfg)):
             raise ValueError('a pipeline takes equally shaped batches; flush() before changing shape')
         if self._outputs[slot] is None or self._outputs[slot][0].shape[0] != B:
-            self._outputs[slot] = hd._alloc_outputs(B, self.max_boxes, dev, self.want_cc)
+            with _allocating_on(self.stream):
+                self._outputs[slot] = hd._alloc_outputs(B, self.max_boxes, dev, self.want_cc)
         arr = _abi.pointer_array([h.data_ptr() for h in heads])
         args = self._args(cfg, arr, B, cap, ws.data_ptr(),
                           prev[2].data_ptr() if prev is not None else None, ws.numel(),

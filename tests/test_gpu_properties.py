@@ -327,3 +327,83 @@ def test_lanes_match_detect_on_random_heads(gpu, geo, B, batches, lanes, thr, mb
             assert torch.equal(gc, wc), i
     finally:
         _abi.set_tuning()
+
+
+@settings(max_examples=examples(10), **SETTINGS)
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, MAX_B), version=st.sampled_from([2, 3]),
+       thr=st.sampled_from([0.3, 0.5, 0.6]), steps=st.integers(2, 6))
+def test_loss_call_sequences_on_one_workspace(gpu, data, geo, B, version, thr, steps):
+    """A training loop's calls on ONE head object (one workspace, whose ground-truth tables are read back
+    through the scalar data cache): every step has new ground truth, is prepared ahead or not, asks for
+    the gradient or not; every step's outputs are those of a fresh head object given the same inputs,
+    bit for bit (no table, count or prepared state of an earlier step is seen by a later one)."""
+    case, seed = geo
+    norm = version == 3
+    scales = (1.0, 0.5, 5.0, 2.0)
+    pad = data.draw(st.integers(2, MAX_PAD))
+    dheads = to_dev(case.heads(seed % 7901, B, obj_mean=-1.0), gpu)
+    gw = torch.linspace(0.25, 1.5, B, device=gpu)
+    hd = case.head_obj()
+    plan = []
+    for i in range(steps):
+        rng = np.random.Generator(np.random.PCG64(seed + 17 * i))
+        gt = np.full((B, pad, 5), -1.0, np.float32)
+        for b in range(B):
+            G = int(rng.integers(1, pad))
+            gt[b, :G, 0:2] = rng.uniform(0.0, case.size, size=(G, 2))
+            gt[b, :G, 2:4] = np.exp(rng.uniform(np.log(2.0), np.log(case.size), size=(G, 2)))
+            gt[b, :G, 4] = rng.integers(0, case.C, size=G)
+        plan.append((torch.from_numpy(gt).to(gpu), data.draw(st.booleans()), data.draw(st.booleans()), data.draw(st.booleans())))
+    got = []
+    for dgt, prepare, grad, stale in plan:                      # back to back, nothing but the stream's order between the calls
+        if prepare:
+            if stale:                                           # a preparation that is never used: other ground truth follows
+                hd.loss_prepare(dheads, plan[0][0])
+            hd.loss_prepare(dheads, dgt)
+        out = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_mask=not grad, grad_per_image=gw if grad else None)
+        got.append({k: ([g.clone() for g in v] if k == 'grads' else v.clone()) for k, v in out.items() if v is not None})
+
+    def same(a, b):
+        return a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=7e30, neginf=-7e30),
+                                                  torch.nan_to_num(b, nan=-7.0, posinf=7e30, neginf=-7e30))
+    for i, ((dgt, prepare, grad, stale), g) in enumerate(zip(plan, got)):
+        w = case.head_obj().loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_mask=not grad,
+                                 grad_per_image=gw if grad else None)
+        for k in ('per_image', 'sum', 'parts') + (('grads',) if grad else ('noobj_mask',)):
+            if k == 'grads':
+                assert all(same(a, b) for a, b in zip(g[k], w[k])), (i, k, prepare, stale)
+            else:
+                assert same(g[k], w[k]), (i, k, prepare, stale)
+
+
+@settings(max_examples=examples(8), **SETTINGS)
+@given(geos=st.lists(geometries(), min_size=2, max_size=5), data=st.data())
+def test_static_scratch_on_random_call_sequences(gpu, geos, data):
+    """yh_detect_static (the library's own scratch array instead of a workspace) called for a sequence of
+    unrelated shapes, capacities and thresholds in a row: each call finds the leftovers of the one before
+    where its counters lie, and gives yh_detect's outputs on a fresh workspace, bit for bit."""
+    from yolo_tf_amd import _abi
+    for case, seed in geos:
+        B = data.draw(st.integers(1, 3))
+        thr = data.draw(st.sampled_from([1e-3, 0.05, 0.3, 0.5]))
+        mb = data.draw(st.sampled_from([3, 10, 100]))
+        cap = data.draw(st.sampled_from([8, 512, 2048, 6000]))
+        cap = max(1, min(cap, case.N * case.C))
+        dheads = to_dev(case.heads(seed % 9923, B, obj_mean=data.draw(st.sampled_from([-3.0, 0.0, 3.0])), cold_mean=-2.0), gpu)
+        hd = case.head_obj()
+        want = hd.detect(dheads, thr, 0.5, mb, max_candidates=cap, want_class_candidates=True)
+        outs = hd._alloc_outputs(B, mb, gpu, True)
+        try:
+            got = hd.detect_static(dheads, thr, 0.5, mb, cap, outs)
+        except _abi.YhError as e:                                # a shape beyond the array: said so, nothing ran
+            assert e.code == _abi.YH_ERR_LIMIT
+            continue
+        assert torch.equal(got.status, want.status)
+        assert torch.equal(got.class_candidates, want.class_candidates) or want.overflowed()
+        if want.overflowed():
+            continue
+        count = want.count.cpu().numpy()
+        assert np.array_equal(got.count.cpu().numpy(), count)
+        for b, k in enumerate(count):
+            for a, w in ((got.scores, want.scores), (got.boxes, want.boxes), (got.class_id, want.class_id), (got.index, want.index)):
+                assert np.array_equal(a[b, :k].cpu().numpy().view(np.uint32), w[b, :k].cpu().numpy().view(np.uint32)), (case.grids, b)

@@ -1291,6 +1291,59 @@ def test_class_api_v2(gpu, c_oracle, capsys):
     assert_close(mean_loss, np.mean(wants), what='epoch mean loss')
 
 
+def test_host_threads_call_the_library_at_once(gpu):
+    """Three host threads, each with a stream, head objects and inputs of its own, call detect (default
+    and dense capacity), the loss with its preparation and the fused gradient at the same time (ctypes
+    releases the interpreter lock during a call): the library's host-side tables (prepared losses,
+    streaming calls per workspace, LDS limits, tickets) are shared by them; every result is the one the
+    thread's inputs give alone."""
+    import threading
+    case = cases.v3(size=160, C=20)
+    B, G, pad = 3, 6, 9
+    inputs, want = [], []
+    for t in range(3):
+        heads = y.synth.torch_heads(gpu, 700 + t, B, case.grids, case.P, case.C, obj_mean=-1.0)
+        gt = torch.from_numpy(y.synth.make_ground_truth(710 + t, B, G, pad, 160, case.C)).to(gpu)
+        hd = case.head_obj()
+        d = hd.detect(heads, 0.3, 0.5, 10)
+        dense = hd.detect(heads, 0.05, 0.5, 10, max_candidates=4096)
+        l = hd.loss(heads, gt, 1., 1., 5., 1., 0.5, True, grad_per_image=torch.ones(B, device=gpu))
+        inputs.append((heads, gt))
+        want.append((d.per_image(), dense.per_image(), l['per_image'].clone(), [g.clone() for g in l['grads']]))
+    torch.cuda.synchronize(gpu)
+    errors = []
+
+    def work(t):
+        try:
+            heads, gt = inputs[t]
+            stream = torch.cuda.Stream(gpu)
+            with torch.cuda.stream(stream):
+                hd = case.head_obj()
+                gw = torch.ones(B, device=gpu)
+                for it in range(150):
+                    d = hd.detect(heads, 0.3, 0.5, 10)
+                    dense = hd.detect(heads, 0.05, 0.5, 10, max_candidates=4096)
+                    if it % 2:
+                        hd.loss_prepare(heads, gt)
+                    l = hd.loss(heads, gt, 1., 1., 5., 1., 0.5, True, grad_per_image=gw)
+                    if it % 25 == 24:
+                        stream.synchronize()
+                        cases.same_detections(d.per_image(), want[t][0])
+                        cases.same_detections(dense.per_image(), want[t][1])
+                        assert torch.equal(l['per_image'], want[t][2]), it
+                        assert all(torch.equal(a, b) for a, b in zip(l['grads'], want[t][3])), it
+                stream.synchronize()
+        except BaseException as e:                              # reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_abi_rejects_bad_arguments(gpu):
     case = cases.v2()
     hd = case.head_obj()

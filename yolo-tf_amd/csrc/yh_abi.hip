@@ -1021,10 +1021,14 @@ static uint64_t config_hash(const yh_head_config *cfg)
 static void record_prepared(const void *ws, const float *gt, int32_t batch, int32_t pad, uint64_t hash)
 {
     std::lock_guard<std::mutex> lock(g_prepared_mu);
-    int at = -1;
-    for (int i = 0; i < kPreparedLosses && at < 0; ++i)
+    int at = -1, empty = -1;
+    for (int i = 0; i < kPreparedLosses && at < 0; ++i) {
         if (g_prepared[i].ws == ws) at = i;
-    if (at < 0) at = (int)(g_prepared_next++ % kPreparedLosses);
+        if (empty < 0 && g_prepared[i].ws == nullptr) empty = i;
+    }
+    // a free cell if there is one; with kPreparedLosses preparations outstanding one of them is forgotten (its loss
+    // call then builds the tables itself)
+    if (at < 0) at = empty >= 0 ? empty : (int)(g_prepared_next++ % kPreparedLosses);
     g_prepared[at] = PreparedLoss{ws, gt, batch, pad, hash};
 }
 

@@ -201,3 +201,37 @@ def test_records_to_training_step_end_to_end(tmp_path):
     net = y.YOLOv2(cfg, prov)
     losses = [float(net.train_one_epoch(1e-3)) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_example_codec_round_trips_random_features():
+    """encode_example -> decode_example gives the features back: byte lists (empty strings, empty lists), float32
+    arrays (non-finite values by bit pattern), int64 arrays up to both ends of the range; through a record file too."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    import tempfile
+    names = st.text(min_size=1, max_size=12)
+    value = st.one_of(
+        st.lists(st.binary(max_size=40), max_size=5),
+        st.lists(st.floats(width=32, allow_nan=True, allow_infinity=True), max_size=20).map(lambda v: np.asarray(v, np.float32)),
+        st.lists(st.integers(-2 ** 63, 2 ** 63 - 1), max_size=20).map(lambda v: np.asarray(v, np.int64)))
+
+    @settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(features=st.dictionaries(names, value, max_size=6))
+    def check(features):
+        record = records.encode_example(features)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, 'one.tfrecord')
+            with records.TFRecordWriter(path) as w:
+                w.write(record)
+                w.write(b'')
+            back = list(records.read_tfrecords(path, verify=True))
+        assert back == [record, b'']
+        got = records.decode_example(back[0])
+        assert set(got) == set(features)
+        for name, v in features.items():
+            if isinstance(v, list):
+                assert got[name] == v
+            elif v.dtype == np.float32:
+                assert got[name].dtype == np.float32 and np.array_equal(got[name].view(np.uint32), v.view(np.uint32))
+            else:
+                assert got[name].dtype == np.int64 and np.array_equal(got[name], v)
+    check()

@@ -246,3 +246,55 @@ def test_sigmoid_and_cross_entropy_against_torch():
     assert np.all(np.abs(O.sigmoid_ce(x, z).astype(np.float64) - want_ce) <= bound)
     f32 = F.binary_cross_entropy_with_logits(torch.from_numpy(x), torch.from_numpy(z), reduction='none').numpy()
     assert np.all(np.abs(O.sigmoid_ce(x, z).astype(np.float64) - f32) <= 2 * bound)
+
+
+def test_restatements_agree_on_random_sizes_and_ground_truth(c_oracle):
+    """The C restatement and the NumPy restatement, written independently from the reference's text, on random
+    image sizes, class counts and ground truth (duplicated rows, rows sharing a cell, boxes of a few pixels and
+    of the whole image): decode 1e-5, the same kept rows and classes, per-image losses 1e-5, ignore-mask IoU
+    maxima bit for bit; v3 and v2."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=int(__import__('os').environ.get('YH_PROPERTY_EXAMPLES', '0')) or 40, deadline=None, derandomize='YH_PROPERTY_EXAMPLES' not in __import__('os').environ, suppress_health_check=list(HealthCheck))
+    @given(version=st.sampled_from([2, 3]), cells=st.integers(1, 5), C=st.sampled_from([1, 3, 20, 80]),
+           B=st.integers(1, 2), G=st.integers(1, 12), seed=st.integers(0, 10 ** 6), thr=st.sampled_from([0.1, 0.3, 0.5]))
+    def check(version, cells, C, B, G, seed, thr):
+        size = 32 * cells
+        case = cases.v3(size=size, C=C) if version == 3 else cases.v2(size=size, C=C)
+        heads = case.heads(seed, B, obj_mean=0.0, cold_mean=-2.0)
+        cfg = case.oracle_cfg(c_oracle)
+        cb, cc = c_oracle.decode(cfg, heads)
+        got = c_oracle.detect(cfg, heads, thr, 0.5, 5)
+        for b in range(B):
+            nb, nc = O.decode([h[b] for h in heads], case.priors, case.box_mult, case.C)
+            np.testing.assert_allclose(cb[b], nb, rtol=1e-5, atol=1e-5 * size)
+            np.testing.assert_allclose(cc[b], nc, rtol=1e-5, atol=1e-30)
+            # the walk on the C restatement's own decoded arrays: the same comparisons, so the same rows
+            s, bx, cl, ix = O.nms_per_class(cb[b], cc[b], thr, 5, 0.5)
+            assert np.array_equal(ix, got[b][3]) and np.array_equal(cl, got[b][2])
+        rng = np.random.Generator(np.random.PCG64(seed + 1))
+        gt = np.full((B, G + 2, 5), -1.0, np.float32)
+        for b in range(B):
+            yx = rng.uniform(0.0, size, size=(G, 2))
+            hw = np.exp(rng.uniform(np.log(2.0), np.log(size), size=(G, 2)))
+            for g in range(1, G):
+                if rng.integers(0, 4) == 0:                  # a copy of an earlier row, or a row in its cell
+                    j = int(rng.integers(0, g))
+                    yx[g] = yx[j]
+                    if rng.integers(0, 2):
+                        hw[g] = hw[j]
+            gt[b, :G, 0:2], gt[b, :G, 2:4] = yx, hw
+            gt[b, :G, 4] = rng.integers(0, C, size=G)
+        scales = (1., 1., 5., 1.)
+        if version == 3:
+            per, parts, iou, mean = c_oracle.loss(cfg, heads, gt, scales, 0.5, True, want_iou=True)
+            nper, nmean = O.loss_v3_batch(heads, gt, case.priors, case.C)
+            for b in range(B):
+                ni = O.noobj_iou_max([h[b] for h in heads], gt[b], case.priors, case.gt_rate, case.C)
+                assert np.array_equal(ni.view(np.uint32), iou[b].view(np.uint32))
+        else:
+            per, parts, iou, mean = c_oracle.loss(cfg, heads, gt, scales, 0.6, False)
+            nper, nmean = O.loss_v2_batch(heads[0], gt, case.priors[0], case.C)
+        np.testing.assert_allclose(per, nper, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mean, nmean, rtol=1e-5, atol=1e-6)
+    check()

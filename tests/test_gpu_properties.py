@@ -408,3 +408,59 @@ def test_static_scratch_on_random_call_sequences(gpu, geos, data):
         for b, k in enumerate(count):
             for a, w in ((got.scores, want.scores), (got.boxes, want.boxes), (got.class_id, want.class_id), (got.index, want.index)):
                 assert np.array_equal(a[b, :k].cpu().numpy().view(np.uint32), w[b, :k].cpu().numpy().view(np.uint32)), (case.grids, b)
+
+
+@settings(max_examples=examples(8), **SETTINGS)
+@given(version=st.sampled_from([2, 3]), cells=st.integers(1, 8), C=st.sampled_from([1, 2, 20, 80]),
+       fmt=st.sampled_from(['channels_last', 'channels_first']), Bt=st.integers(1, 5), iters=st.integers(1, 3),
+       thr=st.sampled_from([0.05, 0.3, 0.5]), iou=st.sampled_from([0.3, 0.5]), mb=st.sampled_from([1, 10, 50]),
+       w=st.tuples(st.sampled_from([1., 2.]), st.sampled_from([1., .5]), st.sampled_from([5., 1.]), st.sampled_from([1., 3.])),
+       seed=st.integers(0, 10 ** 6))
+def test_class_api_on_random_configs(gpu, c_oracle, version, cells, C, fmt, Bt, iters, thr, iou, mb, w, seed):
+    """The YOLOv3 / YOLOv2 classes over random configuration dicts (image size, class count, data format,
+    thresholds, loss scales, batch size): test_one_image gives, for image 0, the bits of the head path set up
+    independently for the same geometry; train_one_epoch's mean over the iterations is the oracle's (.5 * total_loss for
+    v3, total_loss for v2)."""
+    import contextlib, io
+    size = 32 * cells
+    case = cases.v3(size=size, C=C) if version == 3 else cases.v2(size=size, C=C)
+    cfg = dict(mode='test', data_shape=[size, size, 3], num_classes=C, weight_decay=5e-4, keep_prob=0.5,
+               data_format=fmt, batch_size=Bt, coord_scale=w[0], noobj_scale=w[1], obj_scale=w[2], class_scale=w[3],
+               nms_score_threshold=thr, nms_max_boxes=mb, nms_iou_threshold=iou,
+               priors=y.synth.V3_PRIORS if version == 3 else y.synth.V2_PRIORS)
+    if version == 3:
+        cfg['num_priors'] = 3
+    else:
+        cfg.update(is_pretraining=False, rescore_confidence=False)
+    cls = y.YOLOv3 if version == 3 else y.YOLOv2
+
+    def given_as(hs):                                           # the layout the configuration announces
+        hs = [h.permute(0, 3, 1, 2).contiguous() if fmt == 'channels_first' else h for h in hs]
+        return hs if version == 3 else hs[0]
+
+    heads = case.heads(seed % 9941, 2, obj_mean=0.0, cold_mean=-2.0)
+    pred = cls(cfg, None).test_one_image(given_as(to_dev(heads, gpu)))
+    # image 0 through a head object built from the case's own priors and multipliers (the class derives its from
+    # the configuration): the same bits; that path is held to the oracle by the properties above
+    want = case.head_obj().detect(to_dev([h[:1] for h in heads], gpu), thr, iou, mb).per_image()[0]
+    event('detections of image 0: %s' % ('none' if len(want[0]) == 0 else 'some'))
+    assert pred[0].dtype == np.float32 and pred[1].dtype == np.float32 and pred[2].dtype == np.int32
+    assert np.array_equal(pred[2], want[2])
+    assert np.array_equal(pred[0].view(np.uint32), want[0].view(np.uint32))
+    assert np.array_equal(pred[1].view(np.uint32), want[1].view(np.uint32))
+    G = 1 + seed % 7
+    batches = [(given_as(to_dev(case.heads((seed + 7 * i) % 9931, Bt, obj_mean=-1.0), gpu)),
+                torch.from_numpy(case.gt(seed + 13 * i, Bt, G, G + 3)).to(gpu)) for i in range(iters)]
+    provider = dict(data_shape=[size, size, 3], num_train=iters * Bt, num_val=0,
+                    train_generator=(None, iter(batches)), val_generator=None)
+    net = cls(dict(cfg, mode='train', batch_size=Bt), provider)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mean_loss = net.train_one_epoch(1e-3)
+    wants = []
+    for i in range(iters):
+        hs = [h for h in case.heads((seed + 7 * i) % 9931, Bt, obj_mean=-1.0)]
+        m = c_oracle.loss(case.oracle_cfg(c_oracle), hs, case.gt(seed + 13 * i, Bt, G, G + 3), w,
+                          0.5 if version == 3 else 0.6, version == 3)[3]
+        wants.append(np.float32(0.5) * m if version == 3 else m)
+    assert_close(mean_loss, np.mean(wants), rtol=2 * RTOL, what='epoch mean loss')
+

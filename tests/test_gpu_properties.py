@@ -464,3 +464,56 @@ def test_class_api_on_random_configs(gpu, c_oracle, version, cells, C, fmt, Bt, 
         wants.append(np.float32(0.5) * m if version == 3 else m)
     assert_close(mean_loss, np.mean(wants), rtol=2 * RTOL, what='epoch mean loss')
 
+
+
+@settings(max_examples=examples(8), **SETTINGS)
+@given(geo=geometries(), B=st.integers(1, 3), batches=st.integers(2, 6), thr=st.sampled_from([1e-3, 0.05, 0.3, 0.5]),
+       mb=st.sampled_from([3, 10, 100]), obj_mean=st.sampled_from([-3.0, 0.0, 3.0]),
+       cap_kind=st.sampled_from(['default', 'one launch', 'every pair']), kernel=st.sampled_from([0, 1, 2]))
+def test_candidates_and_select_on_two_streams(gpu, geo, B, batches, thr, mb, obj_mean, cap_kind, kernel):
+    """yh_detect as its two calls on two streams, as a serving loop overlaps them: yh_detect_candidates of batch
+    i on one stream, yh_detect_select of batch i on the other behind an event, two workspaces taking turns (a
+    workspace's next streaming call waits for its select).  Every batch's outputs are yh_detect's."""
+    import ctypes
+    from yolo_tf_amd import _abi
+    case, seed = geo
+    cap = {'default': min(512, case.N * case.C), 'one launch': min(case.N * case.C, 2048), 'every pair': case.N * case.C}[cap_kind]
+    lib = _abi.load()
+    try:
+        _abi.set_tuning(detect_kernel=kernel)
+        sets = [to_dev(case.heads((seed + 37 * i) % 9929, B, obj_mean=obj_mean, cold_mean=-2.0), gpu) for i in range(batches)]
+        hd = case.head_obj()
+        want = [hd.detect(h, thr, 0.5, mb, max_candidates=cap, want_class_candidates=True) for h in sets]
+        cfg = hd.config_for(sets[0])
+        nbytes = ctypes.c_size_t(0)
+        _abi.check(lib.yh_detect_workspace_bytes(ctypes.byref(cfg), B, cap, mb, ctypes.byref(nbytes)))
+        s_cand, s_sel = torch.cuda.Stream(gpu), torch.cuda.Stream(gpu)
+        with torch.cuda.stream(s_cand):
+            wss = [torch.zeros(max(256, nbytes.value), dtype=torch.uint8, device=gpu) for _ in range(2)]
+        outs = [hd._alloc_outputs(B, mb, gpu, True) for _ in range(batches)]
+        torch.cuda.synchronize(gpu)
+        ev_c = [torch.cuda.Event() for _ in range(2)]
+        ev_s = [torch.cuda.Event() for _ in range(2)]
+        for i, h in enumerate(sets):
+            k = i & 1
+            s_cand.wait_event(ev_s[k])                         # the workspace's last select has read it (no-op at first)
+            _abi.check(lib.yh_detect_candidates(ctypes.byref(cfg), _abi.pointer_array([t.data_ptr() for t in h]), B, thr, mb, cap,
+                                                wss[k].data_ptr(), wss[k].numel(), ctypes.c_void_p(s_cand.cuda_stream)))
+            ev_c[k].record(s_cand)
+            s_sel.wait_event(ev_c[k])
+            _abi.check(lib.yh_detect_select(ctypes.byref(cfg), B, 0.5, mb, cap, wss[k].data_ptr(), wss[k].numel(),
+                                            *[t.data_ptr() for t in outs[i]], ctypes.c_void_p(s_sel.cuda_stream)))
+            ev_s[k].record(s_sel)
+        torch.cuda.synchronize(gpu)
+        for i, w in enumerate(want):
+            g = y.Detections(*outs[i], None)
+            assert torch.equal(g.status, w.status), i
+            if w.overflowed():
+                continue
+            assert torch.equal(g.class_candidates, w.class_candidates), i
+            cases.same_detections(g.per_image(), w.per_image())
+            for a, b in zip(g.per_image(), w.per_image()):
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), i
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), i
+    finally:
+        _abi.set_tuning()

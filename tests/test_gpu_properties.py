@@ -517,3 +517,84 @@ def test_candidates_and_select_on_two_streams(gpu, geo, B, batches, thr, mb, obj
                 assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), i
     finally:
         _abi.set_tuning()
+
+
+@settings(max_examples=examples(10), **SETTINGS)
+@given(geo=geometries(max_classes=90), B=st.integers(1, 2), thr=st.sampled_from([1e-3, 0.3, 0.5]), mb=st.sampled_from([3, 10]),
+       share=st.sampled_from([0.001, 0.02, 0.3]), seed2=st.integers(0, 10 ** 6))
+def test_detect_with_special_values_in_the_head(gpu, c_oracle, geo, B, thr, mb, share, seed2):
+    """Head tensors with infinities, NaN, huge and denormal logits scattered over every channel: the decode has
+    the oracle's NaN and infinity pattern and its finite values to 1e-5; score filter and NMS on the GPU's own
+    decoded arrays are the oracle's bit for bit (NaN confidences are no candidates, NaN and infinite boxes
+    suppress nothing); the fused call and every streaming kernel give the staged result."""
+    from yolo_tf_amd import _abi
+    case, seed = geo
+    heads = case.heads(seed % 9913, B, obj_mean=0.0, cold_mean=-2.0)
+    rng = np.random.Generator(np.random.PCG64(seed2))
+    special = np.array([np.inf, -np.inf, np.nan, 1e30, -1e30, 1e-40, -1e-40, 88.0, -88.0, 104.0, -104.0, 0.0], np.float32)
+    for h in heads:
+        m = rng.uniform(size=h.shape) < share
+        h[m] = rng.choice(special, size=int(m.sum()))
+    dheads = to_dev(heads, gpu)
+    hd = case.head_obj()
+    boxes, conf = hd.decode(dheads)
+    wb, wc = c_oracle.decode(case.oracle_cfg(c_oracle), heads)
+    assert_close(boxes.cpu().numpy(), wb, rtol=RTOL, atol=RTOL * case.size * 4, what='boxes')
+    assert_close(conf.cpu().numpy(), wc, rtol=RTOL, atol=1e-30, what='conf')
+    hb, hc = boxes.cpu().numpy(), conf.cpu().numpy()
+    staged = hd.nms(boxes, conf, thr, 0.5, mb, want_class_candidates=True).resolved()
+    got = staged.per_image()
+    cases.same_detections(got, c_oracle.nms(hb, hc, thr, 0.5, mb))
+    assert np.array_equal(staged.class_candidates.cpu().numpy(), (hc >= np.float32(thr)).sum(axis=1).astype(np.int32))
+    try:
+        for t in (dict(), dict(row_steps=2), dict(detect_kernel=2, stream_tile_kib=1),
+                  dict(detect_kernel=2, stream_tile_kib=4, stream_buffers=2, stream_units=300)):
+            _abi.set_tuning(**t)
+            for cap in (None, case.N * case.C):
+                fused = case.head_obj().detect(dheads, thr, 0.5, mb, max_candidates=cap, want_class_candidates=True).resolved()
+                cases.same_detections(fused.per_image(), got)
+                for f, g in zip(fused.per_image(), got):
+                    assert np.array_equal(f[0].view(np.uint32), g[0].view(np.uint32)), (t, cap)
+                    assert np.array_equal(f[1].view(np.uint32), g[1].view(np.uint32)), (t, cap)
+                assert torch.equal(fused.class_candidates, staged.class_candidates), (t, cap)
+    finally:
+        _abi.set_tuning()
+
+
+@settings(max_examples=examples(10), **SETTINGS)
+@given(data=st.data(), geo=geometries(max_classes=90), B=st.integers(1, 4), version=st.sampled_from([2, 3]),
+       share=st.sampled_from([0.0005, 0.01, 0.2]), seed2=st.integers(0, 10 ** 6))
+def test_loss_with_special_values_in_the_head(gpu, c_oracle, data, geo, B, version, share, seed2):
+    """The loss of head tensors with infinities, NaN, huge and denormal logits: per-image losses and parts have
+    the oracle's NaN and infinity pattern and its finite values to 1e-5 (an image without such a logit in a term
+    keeps a finite term); the fused gradient pass, the two calls and the prepared call agree bit for bit."""
+    case, seed = geo
+    gt = data.draw(ground_truths(case, B))
+    heads = case.heads(seed % 7877, B, obj_mean=-1.0)
+    rng = np.random.Generator(np.random.PCG64(seed2))
+    special = np.array([np.inf, -np.inf, np.nan, 1e30, -1e30, 1e-40, -1e-40, 88.0, -88.0, 104.0, -104.0, 0.0], np.float32)
+    for h in heads:
+        m = rng.uniform(size=h.shape) < share
+        h[m] = rng.choice(special, size=int(m.sum()))
+    norm, thr = version == 3, 0.5 if version == 3 else 0.6
+    scales = (1.0, 0.5, 5.0, 2.0)
+    dheads, dgt = to_dev(heads, gpu), torch.from_numpy(gt).to(gpu)
+    hd = case.head_obj()
+    out = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, want_mask=True)
+    per, parts, _, _ = c_oracle.loss(case.oracle_cfg(c_oracle), heads, gt, scales, thr, norm)
+    assert_close(out['parts'].cpu().numpy(), parts, rtol=RTOL, atol=1e-6, what='loss parts')
+    assert_close(out['per_image'].cpu().numpy(), per, rtol=RTOL, atol=1e-6, what='per-image loss')
+    gw = torch.linspace(0.25, 1.5, B, device=gpu)
+    two = hd.loss_backward(dheads, dgt, *scales, norm, out['noobj_mask'], gw)
+    fused = hd.loss(dheads, dgt, *scales, thr, norm, want_parts=True, grad_per_image=gw)
+    other = case.head_obj()
+    other.loss_prepare(dheads, dgt)
+    prepared = other.loss(dheads, dgt, *scales, thr, norm, want_parts=True, grad_per_image=gw)
+
+    def same(a, b):
+        return a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=7e30, neginf=-7e30),
+                                                  torch.nan_to_num(b, nan=-7.0, posinf=7e30, neginf=-7e30))
+    for k in ('per_image', 'parts'):
+        assert same(fused[k], out[k]) and same(prepared[k], out[k]), k
+    for s in range(len(two)):
+        assert same(fused['grads'][s], two[s]) and same(prepared['grads'][s], two[s]), s

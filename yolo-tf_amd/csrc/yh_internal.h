@@ -42,15 +42,17 @@ __device__ inline float key_score(unsigned long long k)
 // (and that of the constant) into the exponent, a relative error that grows as 8e-8 |x| and passes
 // 5e-6 at the largest finite results.  The product is therefore taken in two parts: p = RN(x * hi),
 // d = the exact remainder x * hi - p plus x * lo (hi + lo = log2(e) to 2^-50), and
-// exp2(p + d) = exp2(p) * (1 + d ln 2) with |d| < 2^-17: three ulp whatever |x| is.  An overflowing
-// exp2(p) stays +inf (the factor is within 1e-5 of one) and an underflowing one stays 0.
+// exp2(p + d) = exp2(p) * (1 + d ln 2) with |d| < 2^-17 while the result is finite: three ulp whatever |x| is.
+// Beyond that d means nothing (for |x| of 1e30 it is huge, for an infinite x it is inf - inf), so it is held
+// inside +-2^-10: an overflowing exp2(p) stays +inf, an underflowing one 0, exp(+-inf) is +inf / 0 as the
+// reference's, and a NaN logit stays NaN through exp2(p).
 // Every decode kernel uses these two functions, so the staged and the fused paths agree bit for bit.
 __device__ __forceinline__ float decode_exp(float x)
 {
     const float hi = 1.44269502162933349609375f;        // RN(log2 e)
     const float lo = 1.92596299112661747e-8f;             // log2 e - hi
     const float p = x * hi;
-    const float d = __builtin_fmaf(x, lo, __builtin_fmaf(x, hi, -p));
+    const float d = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, lo, __builtin_fmaf(x, hi, -p)), -0x1p-10f, 0x1p-10f);   // a NaN d: one of the bounds
     return __builtin_amdgcn_exp2f(p) * __builtin_fmaf(d, 0.693147180559945309417f, 1.0f);
 }
 __device__ __forceinline__ float decode_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + decode_exp(-x)); }

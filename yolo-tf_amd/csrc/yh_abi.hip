@@ -110,7 +110,8 @@ DetectWs carve_detect(void *base, int64_t B, int64_t N, int64_t C, int64_t cap, 
     DetectWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    char *p = static_cast<char *>(base);
+    // the base may be null (a size query): offsets are added to its integer value, not to the pointer
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
     const size_t o_cand = take((size_t)B * cap * 8), o_seg = take((size_t)B * cap * 8);
     const size_t o_box = row_boxes ? take((size_t)B * N * 16) : 0;
     const size_t o_cbox = cand_boxes ? take((size_t)B * cap * 16) : 0;
@@ -981,7 +982,7 @@ static LossWs carve_loss(void *base, const yh::LossParams &p)
     LossWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    char *c = static_cast<char *>(base);
+    const uintptr_t c = reinterpret_cast<uintptr_t>(base);      // may be null (a size query)
     const size_t o_pair = take(2 * sizeof(double));            // offset 0: documented in yolohead.h
     const size_t o_neg = take((size_t)p.B * p.blocks_per_img * 4);
     const size_t o_pos = take((size_t)p.B * p.pos_blocks * 3 * 4);

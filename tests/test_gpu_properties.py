@@ -87,7 +87,7 @@ def ground_truths(draw, case, B):
     rng = np.random.Generator(np.random.PCG64(seed))
     gt = np.full((B, pad, 5), -1.0, np.float32)
     for b in range(B):
-        G = int(rng.integers(1, pad))                          # at least one row, at least one pad row
+        G = int(rng.integers(0 if SOAK else 1, pad))           # at least one pad row; the soak also draws images without any row
         yx = rng.uniform(-0.1 * case.size, 1.1 * case.size, size=(G, 2))
         hw = np.exp(rng.uniform(np.log(2.0), np.log(case.size), size=(G, 2)))
         kind = rng.integers(0, 6, size=G)

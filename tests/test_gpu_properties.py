@@ -598,3 +598,32 @@ def test_loss_with_special_values_in_the_head(gpu, c_oracle, data, geo, B, versi
         assert same(fused[k], out[k]) and same(prepared[k], out[k]), k
     for s in range(len(two)):
         assert same(fused['grads'][s], two[s]) and same(prepared['grads'][s], two[s]), s
+
+
+@settings(max_examples=min(examples(5), 300), **SETTINGS)
+@given(n=st.integers(2, 4), cin=st.integers(1, 9), cout=st.integers(1, 9), k=st.sampled_from([1, 3]), stride=st.sampled_from([1, 2]),
+       h=st.integers(1, 13), w=st.integers(1, 13), act=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_conv_layer_on_random_shapes(gpu, n, cin, cout, k, stride, h, w, act, seed):
+    """backbone.ConvBN on MIOpen (channels_last) against the independent NumPy float64 restatement of the
+    reference's _conv_layer (TensorFlow 'same' padding for odd and even sizes at both strides, bias, batch-statistics
+    normalisation with epsilon 1e-3, leaky ReLU 0.1) on random shapes: 1e-4."""
+    import importlib.util, os
+    from yolo_tf_amd import backbone as bb
+    spec = importlib.util.spec_from_file_location(
+        'make_conv_golden', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'make_conv_golden.py'))
+    gold = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gold)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    params = gold.Params(rng)
+    params.conv_bn('l', cin, cout, k)
+    x = rng.normal(0, 1, size=(n, cin, h, w))
+    want = params.layer('l', x, stride=stride, activation=act)
+    layer = bb.ConvBN(cin, cout, k, stride, activation=act)
+    state = layer.state_dict()
+    for name in ('conv.weight', 'conv.bias', 'bn.weight', 'bn.bias'):
+        state[name] = torch.from_numpy(params.store['l.' + name]).to(state[name].dtype)
+    layer.load_state_dict(state)
+    layer = layer.train().to(gpu)
+    got = layer(torch.from_numpy(x).float().to(gpu).contiguous(memory_format=torch.channels_last))
+    assert tuple(got.shape) == want.shape
+    np.testing.assert_allclose(got.detach().float().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
